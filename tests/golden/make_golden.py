@@ -1,0 +1,104 @@
+"""Generates the committed golden fixtures.  Run ONLY in the build container (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+Fixtures written next to this file:
+
+* ``lr_history.json``    — the ``lr`` columns of the reference's own run logs
+                           (runs/unet_r34_512/history.json, history_0.json; data, written by
+                           reference train.py:656) + lr0 / T_max.  Pins the cosine schedule.
+* ``metrics_ref.json``   — outputs of the REFERENCE's own ``dice_coef`` / ``iou_coef``
+                           (train.py:230-281) on seeded probability/target tensors.  The reference
+                           module is imported with empty stand-ins for the absent third-party
+                           modules (cv2, albumentations, segmentation_models_pytorch) purely so that
+                           ``import train`` succeeds; only its pure-torch metric functions are called.
+* ``manifest.json``      — state-dict key -> shape list + parameter count (G1).
+* ``oracle_small.npz``   — oracle logits (train- and eval-mode), loss, four named gradients and a
+                           3-step AdamW loss trajectory at N=2, S=64 under seed 42 / data seed 1234
+                           (G2-G4).  Detects drift of the oracle itself.
+
+The reference's source never travels: only these data files do.
+"""
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parents[1]
+REF = Path("/root/reference")
+sys.path.insert(0, str(ROOT))
+
+from oracle import unet_oracle as O  # noqa: E402
+
+
+def lr_history():
+    out = {}
+    for name, lr0 in (("history.json", 5e-5), ("history_0.json", 1e-3)):
+        h = json.load(open(REF / "runs" / "unet_r34_512" / name))
+        out[name] = {"lr0": lr0, "t_max": len(h), "lr": [r["lr"] for r in h]}
+    json.dump(out, open(HERE / "lr_history.json", "w"))
+
+
+def metrics_ref():
+    for mod in ("cv2", "albumentations", "albumentations.pytorch", "segmentation_models_pytorch"):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    sys.modules["albumentations.pytorch"].ToTensorV2 = object
+    sys.path.insert(0, str(REF))
+    nthreads = torch.get_num_threads()
+    import train as ref_train  # reference train.py (sets torch.set_num_threads(4) as a side effect)
+
+    torch.set_num_threads(nthreads)
+    cases = []
+    for seed, n, s, thr in ((0, 2, 32, 0.5), (1, 3, 64, 0.3), (2, 1, 16, 0.9), (3, 4, 32, 0.0)):
+        g = torch.Generator().manual_seed(seed)
+        prob = torch.rand(n, 1, s, s, generator=g)
+        tgt = (torch.rand(n, 1, s, s, generator=g) > thr).float()
+        if seed == 3:
+            tgt.zero_()          # empty-target edge case: eps keeps it finite
+            prob.mul_(0.4)       # and empty prediction -> Dice = IoU = 1
+        cases.append({"seed": seed, "n": n, "s": s, "thr": thr,
+                      "dice": ref_train.dice_coef(prob, tgt), "iou": ref_train.iou_coef(prob, tgt)})
+    json.dump(cases, open(HERE / "metrics_ref.json", "w"), indent=1)
+
+
+def manifest_and_small():
+    O.set_seed(42)
+    model = O.build_model()
+    man = O.state_dict_manifest(model)
+    json.dump({"param_count": sum(p.numel() for p in model.parameters()), "entries": man},
+              open(HERE / "manifest.json", "w"))
+
+    x, y = O.synthetic_batch(2, 64, seed=1234)
+    model.eval()
+    with torch.no_grad():
+        logits_eval = model(x).numpy()
+    model.train()
+    logits = model(x)
+    loss = O.total_loss(logits, y)
+    loss.backward()
+    named = dict(model.named_parameters())
+    grads = {k: named[k].grad.numpy().copy() for k in (
+        "encoder.conv1.weight", "encoder.layer3.0.downsample.0.weight",
+        "decoder.blocks.3.conv1.0.weight", "segmentation_head.0.bias")}
+    # fresh model for the trajectory so BN running stats start from init
+    O.set_seed(42)
+    model2 = O.build_model()
+    opt = torch.optim.AdamW(model2.parameters(), lr=5e-5, weight_decay=1e-4)
+    traj = O.train_steps(model2, opt, [(x, y)] * 3)
+    np.savez_compressed(
+        HERE / "oracle_small.npz",
+        logits_eval=logits_eval, logits_train=logits.detach().numpy(), loss=np.float64(loss.item()),
+        traj=np.array(traj, dtype=np.float64),
+        bn1_running_mean=model2.encoder.bn1.running_mean.numpy(),
+        **{"grad::" + k: v for k, v in grads.items()})
+
+
+if __name__ == "__main__":
+    lr_history()
+    metrics_ref()
+    manifest_and_small()
+    print("golden fixtures written to", HERE)
