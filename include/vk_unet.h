@@ -1,0 +1,207 @@
+/* vk_unet.h — C ABI of libvkunet.so: the MI355X (gfx950) implementation of the one compute path of
+ * ZooMEISTER/vickers-hardness-Unet: ResNet-34-encoder U-Net forward / BCE+Dice loss / backward /
+ * AdamW on NHWC tensors, as hand-written HIP kernels.
+ *
+ * The reference has no FFI layer of its own: the path sits behind the Python nn.Module / loss /
+ * optimizer protocol.  Each entry point below names the reference call it replaces:
+ *
+ *   vk_unet_create / vk_unet_param_info ....... smp.Unet(...) construction   train.py:372-378, infer_pth_gui.py:31-33
+ *   vk_unet_forward ........................... model(x)                     train.py:436, 510, 693; infer_pth_gui.py:51
+ *   vk_unet_loss .............................. bce(logits,y)+dice(logits,y) train.py:438, 513 (600-601)
+ *   vk_unet_backward .......................... loss.backward()              train.py:443, 448
+ *   vk_adamw_step ............................. optimizer.step()/zero_grad   train.py:428, 449 (606)
+ *   vk_amp_unscale_check ...................... GradScaler.unscale_/step     train.py:443-445 (610-611)
+ *   vk_conv_fwd / vk_conv_wgrad / ... ......... the ATen operators the reference dispatches to
+ *                                               (conv2d, batch_norm, relu, max_pool2d, interpolate, cat)
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary.
+ *   - every device buffer is owned by the caller (PyTorch's allocator in the Python host);
+ *     the library allocates nothing on the device and keeps no pointer after a call returns,
+ *     except those bound to a vk_unet handle by vk_unet_bind (valid until rebind / destroy).
+ *   - all work is enqueued on the hipStream_t passed in (void* stream); no hidden synchronisation.
+ *   - return value: 0 = success, <0 = argument/shape error found on the host (VK_ERR_*),
+ *     >0 = hipError_t from a launch.  vk_last_error_string() gives the text.  Nothing throws.
+ *   - activations are NHWC; weights are KRSC ([K_out][R][S][C_in], i.e. torch channels_last of OIHW).
+ */
+#ifndef VK_UNET_H
+#define VK_UNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VK_ABI_VERSION 1
+
+typedef enum { VK_F32 = 0, VK_BF16 = 1, VK_F16 = 2 } vk_dtype;
+
+enum { VK_OK = 0, VK_ERR_ARG = -1, VK_ERR_STATE = -2, VK_ERR_UNSUPPORTED = -3 };
+
+int vk_version(void);
+const char* vk_last_error_string(void);
+/* 1 if the code object for gfx950 is present in this build (always true for a product build) */
+int vk_has_gfx950_code(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator level (used by the engine below and by the per-kernel parity tests)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One input source of a convolution gather.  The convolution reads a *virtual* input
+ *   V[n][h][w][c] = act( src[n][h >> up][w >> up][c] * scale[c] + shift[c] )
+ * i.e. nearest-x2 upsample (up=1), train/eval BatchNorm apply (scale/shift != NULL) and ReLU (relu=1)
+ * are fused into the operand load; zero padding is applied AFTER that transform. */
+typedef struct {
+  const void* ptr;      /* NHWC, dtype of the conv, [N][H>>up][W>>up][C] */
+  int C;                /* channels of this source (multiple of 8; 16 allowed) */
+  int up;               /* 0 or 1 */
+  const float* scale;   /* [C] or NULL (identity) */
+  const float* shift;   /* [C] or NULL */
+  int relu;             /* apply max(.,0) after the affine */
+} vk_src;
+
+typedef struct {
+  vk_dtype dtype;       /* element type of activations and packed weights */
+  int N, H, W;          /* virtual input spatial size (after the optional upsample) */
+  int Ho, Wo;           /* output spatial size */
+  int K;                /* output channels */
+  int R, S, stride, pad;
+  int transposed;       /* 0: y[p] = sum_r V[p*stride - pad + r] w[r]   (forward)
+                           1: y[p] = sum_r V[(p + pad - r)/stride] w[r] (data gradient; V = dz) */
+  vk_src src0, src1;    /* src1.ptr == NULL when there is no channel concat; C = src0.C + src1.C */
+} vk_conv_desc;
+
+/* y = conv(V, w).  w: [K][R][S][C] of `dtype`.  y: [N][Ho][Wo][K] of `dtype`.
+ * If K >= split_k1 > 0 the output channels [split_k1, K) go to y1 (leading dim K - split_k1) and
+ * [0, split_k1) to y (leading dim split_k1): the two halves of a concat gradient.
+ * accumulate: y (+)= result.  stats: optional double[2][K] receiving sum / sum of squares over
+ * N*Ho*Wo of the stored (rounded) outputs — train-mode BatchNorm partials (must be zeroed by caller). */
+int vk_conv_fwd(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate,
+                double* stats, void* stream);
+
+/* Stem: 7x7 stride-2 pad-3 convolution of x4 [N][H][W][4] (channel 3 is zero padding) with packed
+ * weights wp [64][7][32] (tap row r, 8 columns x 4 channels, zero padded). */
+int vk_stem_fwd(vk_dtype dtype, int N, int H, int W, const void* x4, const void* wp, void* y, double* stats,
+                void* stream);
+
+/* dw[K][R][S][C] (fp32, += via atomics; caller zeroes) = sum_pixels dz[n][p][q][k] * V[n][p*stride-pad+r][..][c] */
+int vk_conv_wgrad(const vk_conv_desc* d, const void* dz, float* dw, void* stream);
+int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const void* dz, float* dw_krsc3, void* stream);
+
+/* NCHW fp32 [N][3][H][W] -> NHWC4 `dtype` */
+int vk_input_transform(vk_dtype dtype, int N, int H, int W, const float* x, void* x4, void* stream);
+
+/* BatchNorm statistics -> per-channel affine.  train=1: from batch sums (count = N*H*W), updates
+ * running stats (momentum 0.1, unbiased var) and writes mean/invstd for backward.  train=0: from
+ * running stats.  scale = gamma*invstd, shift = beta - mean*scale. */
+int vk_bn_finalize(int C, int train, const double* stats, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float eps, float momentum, float* scale, float* shift,
+                   float* save_mean, float* save_invstd, void* stream);
+
+/* pooled = maxpool3x3s2p1(relu(z*scale+shift)); argmax (uint8 0..8, window scan order) kept for backward */
+int vk_bn_relu_maxpool(vk_dtype dtype, int N, int H, int W, int C, const void* z, const float* scale,
+                       const float* shift, void* pooled, uint8_t* argmax, void* stream);
+/* dy[N][H][W][C] += scatter(dpool) through argmax */
+int vk_maxpool_bwd(vk_dtype dtype, int N, int H, int W, int C, const void* dpool, const uint8_t* argmax, void* dy,
+                   void* stream);
+
+/* out = relu(z*scale+shift + (res*rscale+rshift | res)) — BasicBlock tail */
+int vk_bn_add_relu(vk_dtype dtype, size_t pixels, int C, const void* z, const float* scale, const float* shift,
+                   const void* res, const float* rscale, const float* rshift, void* out, void* stream);
+
+/* BatchNorm(+ReLU) backward, two phases.  mask_mode 0: none, 1: relu(z*scale+shift) > 0, 2: mask_src > 0.
+ * phase 1: sums double[2][C] += { sum g, sum g*z },  g = dy * mask.
+ * phase 2 (after vk_bn_bwd_coeffs): dz = a*g + b*z + c ; optional g_out (+)= g  (identity shortcut). */
+int vk_bn_bwd_reduce(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
+                     const float* scale, const float* shift, const void* mask_src, double* sums, void* stream);
+int vk_bn_bwd_coeffs(int C, const double* sums, double count, const float* gamma, const float* save_mean,
+                     const float* save_invstd, float* dgamma, float* dbeta, float* coef_abc, void* stream);
+int vk_bn_bwd_apply(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
+                    const float* scale, const float* shift, const void* mask_src, const float* coef_abc, void* dz,
+                    void* g_out, int g_accumulate, void* stream);
+
+/* d_low[N][H/2][W/2][C] (+)= 2x2 sums of d_up[N][H][W][C] (nearest-x2 upsample backward) */
+int vk_upsample2x_bwd(vk_dtype dtype, int N, int H, int W, int C, const void* d_up, void* d_low, int accumulate,
+                      void* stream);
+
+/* Segmentation head: 3x3 pad-1 conv C=16 -> 1 with bias on the activated decoder output; fp32 logits. */
+int vk_head_fwd(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* bias,
+                float* logits, void* stream);
+int vk_head_bwd(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* dlogits,
+                void* dy, float* dw9x16, float* dbias, void* stream);
+
+/* loss = mean BCE-with-logits + binary Dice (smp defaults: batch-global, smooth 0, eps 1e-7).
+ * sums: double[8] scratch (zeroed by the call).  loss_out[0] = w_bce*bce + w_dice*dice, [1] = bce, [2] = dice.
+ * dlogits (optional) = grad_scale * d(loss_out[0])/dlogits. */
+int vk_bce_dice_loss(size_t count, const float* logits, const float* target, double* sums, float* loss_out,
+                     float* dlogits, float grad_scale, float w_bce, float w_dice, void* stream);
+
+/* AdamW (decoupled decay) over a flat fp32 parameter buffer; optionally emits the 16-bit working copy.
+ * inv_scale multiplies the gradient first (GradScaler unscale / data-parallel averaging).
+ * found_inf (optional int*): when *found_inf != 0 on the device the step is skipped. */
+int vk_adamw_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float inv_scale,
+                  const int* found_inf, void* lowp_copy, vk_dtype lowp_dtype, void* stream);
+/* *found_inf |= any(!isfinite(grad)) */
+int vk_amp_check_inf(size_t n, const float* grad, int* found_inf, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Engine level: the whole network as one plan
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vk_unet vk_unet;
+
+typedef struct {
+  int N, size;          /* batch per GPU and square input size (size % 32 == 0) */
+  vk_dtype dtype;       /* compute/storage type of activations: VK_F32 (exact path) or VK_BF16 / VK_F16 */
+  int training;         /* 1: plan keeps everything backward needs */
+} vk_unet_config;
+
+typedef struct {
+  char name[96];        /* smp state_dict key, e.g. "encoder.layer1.0.conv1.weight" */
+  int kind;             /* 0 conv weight (KRSC in the flat buffer), 1 vector param (bn weight/bias, head bias),
+                           2 fp32 buffer (running_mean/var), 3 int64 buffer (num_batches_tracked) */
+  int dims[4];          /* logical torch shape: OIHW for kind 0, [C] for 1/2, [] for 3 */
+  int ndim;
+  int64_t offset;       /* element offset in the flat param buffer (kind 0/1), the flat fp32 buffer
+                           (kind 2) or the int64 counter array (kind 3) */
+  int64_t numel;
+} vk_tensor_info;
+
+int vk_unet_create(const vk_unet_config* cfg, vk_unet** out);
+void vk_unet_destroy(vk_unet* h);
+int vk_unet_num_tensors(const vk_unet* h);
+int vk_unet_tensor_info(const vk_unet* h, int index, vk_tensor_info* out);
+int64_t vk_unet_param_numel(const vk_unet* h);        /* flat param/grad/moment buffer length (padded) */
+int64_t vk_unet_buffer_numel(const vk_unet* h);       /* flat fp32 BN-buffer length */
+int64_t vk_unet_workspace_bytes(const vk_unet* h);
+/* gradient buckets for data-parallel all-reduce, in backward completion order */
+int vk_unet_num_buckets(const vk_unet* h);
+int vk_unet_bucket_range(const vk_unet* h, int bucket, int64_t* elem_begin, int64_t* elem_end);
+
+/* params/grads: flat fp32 [param_numel]; bn_buffers: flat fp32 [buffer_numel]; nbt: int64[46];
+ * workspace: workspace_bytes.  grads may be NULL for an inference plan. */
+int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_buffers, int64_t* nbt, void* workspace,
+                 size_t workspace_bytes);
+/* re-pack the compute copies of the weights after the fp32 master changed (load_state_dict, optimizer step) */
+int vk_unet_refresh_weights(vk_unet* h, void* stream);
+
+/* x: fp32 NCHW [N][3][S][S]; logits: fp32 [N][1][S][S].  training=1: batch statistics + running-stat update */
+int vk_unet_forward(vk_unet* h, const float* x, float* logits, int training, void* stream);
+/* target fp32 [N][1][S][S]; loss_out float[3]; computes dlogits for backward when the plan is a training plan */
+int vk_unet_loss(vk_unet* h, const float* logits, const float* target, float* loss_out, float grad_scale,
+                 float w_bce, float w_dice, void* stream);
+/* dlogits: fp32 [N][1][S][S] gradient of the loss wrt the logits, or NULL to use the one vk_unet_loss
+ * left in the workspace.  Runs backward stages [stage_begin, stage_end); stage i completes gradient bucket i.  Gradients are
+ * accumulated into the flat grad buffer (caller zeroes it once per step, e.g. via vk_unet_zero_grad). */
+int vk_unet_backward(vk_unet* h, const float* dlogits, int stage_begin, int stage_end, void* stream);
+int vk_unet_zero_grad(vk_unet* h, void* stream);
+
+/* debugging / parity: pointer + shape of a named intermediate ("z:encoder.layer1.0.conv1", "out:encoder.layer1.0", ...) */
+int vk_unet_debug_tensor(const vk_unet* h, const char* name, void** ptr, int dims_nhwc[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VK_UNET_H */

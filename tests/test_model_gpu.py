@@ -1,0 +1,203 @@
+"""Whole-path parity (-m gpu): the HIP engine behind the reference's nn.Module / loss / optimizer
+protocol against the CPU oracle on identical seeded inputs and weights.
+Tolerances: fp32 logits 1e-3 absolute, IoU 1e-4 (BASELINE.json north_star); bf16 stated per test."""
+import importlib
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+vk = importlib.import_module("vickers-hardness-unet_amd")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def pair():
+    from oracle import unet_oracle as O
+    O.set_seed(42)
+    ref = O.build_model()
+    O.set_seed(42)
+    model = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev())
+    return O, ref, model
+
+
+def test_native_library_is_loaded():
+    assert vk.lib().vk_has_gfx950_code() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libvkunet.so" in maps
+
+
+def test_cpu_tensor_fails_loudly(pair):
+    _, _, model = pair
+    with pytest.raises(vk.VkError):
+        model(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 65, 65, device=dev()))
+
+
+@pytest.mark.parametrize("n,s", [(2, 64), (1, 128), (3, 96)])
+def test_eval_logits_fp32(pair, n, s):
+    O, ref, model = pair
+    x, y = O.synthetic_batch(n, s, seed=1234)
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        lo = ref(x)
+        lg = model(x.to(dev())).cpu()
+    assert lg.shape == lo.shape and lg.dtype == torch.float32
+    assert (lg - lo).abs().max().item() <= 1e-3
+    if (n, s) == (2, 64):
+        z = np.load(GOLDEN / "oracle_small.npz")
+        assert np.abs(lg.numpy() - z["logits_eval"]).max() <= 1e-3
+    # mask IoU vs reference masks (threshold 0.5 on sigmoid) within 1e-4
+    po, pg = torch.sigmoid(lo), torch.sigmoid(lg)
+    assert abs(O.iou_coef(pg, y) - O.iou_coef(po, y)) <= 1e-4
+    assert abs(O.dice_coef(pg, y) - O.dice_coef(po, y)) <= 1e-4
+    assert abs(vk.iou_coef(pg.to(dev()), y.to(dev())) - O.iou_coef(pg, y)) <= 1e-6
+
+
+def test_train_forward_backward_fp32(pair):
+    """train-mode logits, loss, every parameter gradient and the BN running statistics."""
+    O, _, _ = pair
+    O.set_seed(42); ref = O.build_model()
+    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
+    x, y = O.synthetic_batch(2, 64, seed=1234)
+    ref.train(); model.train()
+    lo = ref(x)
+    loss_o = O.total_loss(lo, y)
+    loss_o.backward()
+    lg = model(x.to(dev()))
+    loss_g = torch.nn.BCEWithLogitsLoss()(lg, y.to(dev())) + vk.DiceLoss(mode="binary")(lg, y.to(dev()))
+    loss_g.backward()
+    torch.cuda.synchronize()
+    assert (lg.detach().cpu() - lo.detach()).abs().max().item() <= 1e-3
+    z = np.load(GOLDEN / "oracle_small.npz")
+    assert np.abs(lg.detach().cpu().numpy() - z["logits_train"]).max() <= 1e-3
+    assert loss_g.item() == pytest.approx(loss_o.item(), rel=1e-4)
+    named_o = dict(ref.named_parameters())
+    worst = 0.0
+    for k, p in model.named_parameters():
+        go, gg = named_o[k].grad, p.grad.cpu()
+        assert gg.shape == go.shape, k
+        rel = (gg - go).abs().max().item() / (go.abs().max().item() + 1e-12)
+        worst = max(worst, rel)
+        assert rel <= 2e-2, f"{k}: rel grad err {rel}"
+    for k in ("encoder.conv1.weight", "encoder.layer3.0.downsample.0.weight", "decoder.blocks.3.conv1.0.weight"):
+        gref = z["grad::" + k]
+        gg = dict(model.named_parameters())[k].grad.cpu().numpy()
+        assert np.abs(gg - gref).max() <= 2e-2 * np.abs(gref).max()
+    sd_o, sd_g = ref.state_dict(), model.state_dict()
+    for k in sd_o:
+        if "running_" in k:
+            assert (sd_g[k].cpu() - sd_o[k]).abs().max().item() <= 1e-4 * (1 + sd_o[k].abs().max().item()), k
+        if "num_batches_tracked" in k:
+            assert int(sd_g[k]) == int(sd_o[k]) == 1
+
+
+def test_three_step_trajectory_fp32(pair):
+    O, _, _ = pair
+    z = np.load(GOLDEN / "oracle_small.npz")
+    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
+    opt = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=500)
+    x, y = O.synthetic_batch(2, 64, seed=1234)
+    xd, yd = x.to(dev()), y.to(dev())
+    model.train()
+    losses = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        out = model.loss_and_backward(xd, yd)
+        opt.step()
+        losses.append(out[0].item())
+    sched.step()
+    assert opt.param_groups[0]["lr"] == pytest.approx(json.load(open(GOLDEN / "lr_history.json"))["history.json"]["lr"][0], rel=1e-7)
+    assert np.allclose(losses, z["traj"], rtol=2e-3), (losses, z["traj"])
+    assert (model.state_dict()["encoder.bn1.running_mean"].cpu().numpy() - z["bn1_running_mean"]).max() <= 1e-4
+
+
+def test_fused_and_autograd_paths_agree(pair):
+    O, _, _ = pair
+    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
+    x, y = O.synthetic_batch(2, 64, seed=7)
+    xd, yd = x.to(dev()), y.to(dev())
+    model.train()
+    out = model.loss_and_backward(xd, yd)
+    g1 = model.flat_grads.clone()
+    for p in model.parameters():
+        p.grad = None
+    lg = model(xd)
+    loss = vk.BCEDiceLoss()(lg, yd)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert loss.item() == pytest.approx(out[0].item(), rel=1e-5)
+    denom = g1.abs().max().item()
+    assert (model.flat_grads - g1).abs().max().item() <= 1e-4 * denom     # atomics order only
+
+
+def test_bf16_training_step_close_to_fp32_oracle(pair):
+    """bf16 plan (what autocast selects): loss within 2 %, gradients aligned (cosine > 0.98 per large tensor)."""
+    O, _, _ = pair
+    O.set_seed(42); ref = O.build_model()
+    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
+    x, y = O.synthetic_batch(4, 64, seed=1234)
+    ref.train(); model.train()
+    lo = ref(x)
+    loss_o = O.total_loss(lo, y)
+    loss_o.backward()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lg = model(x.to(dev()))
+        loss_g = torch.nn.BCEWithLogitsLoss()(lg, y.to(dev())) + vk.DiceLoss(mode="binary")(lg, y.to(dev()))
+    loss_g.backward()
+    torch.cuda.synchronize()
+    assert lg.dtype == torch.float32
+    assert loss_g.item() == pytest.approx(loss_o.item(), rel=2e-2)
+    assert (lg.detach().cpu() - lo.detach()).abs().max().item() <= 0.15 * lo.abs().max().item()
+    named_o = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        if p.numel() < 4096:
+            continue
+        a, b = p.grad.cpu().flatten().double(), named_o[k].grad.flatten().double()
+        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        assert cos > 0.98, f"{k}: cosine {cos}"
+
+
+def test_state_dict_roundtrip_with_oracle(pair, tmp_path):
+    O, _, _ = pair
+    O.set_seed(1); ref = O.build_model()
+    model = vk.Unet(encoder_weights=None).to(dev())
+    # smp-format checkpoint -> our model (strict), as infer_pth_gui.py:35-43 does
+    torch.save(ref.state_dict(), tmp_path / "last.pth")
+    sd = torch.load(tmp_path / "last.pth", map_location=dev(), weights_only=True)
+    model.load_state_dict(sd, strict=True)
+    x, _ = O.synthetic_batch(1, 64, seed=3)
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        assert (model(x.to(dev())).cpu() - ref(x)).abs().max().item() <= 1e-3
+    # our checkpoint -> oracle (strict)
+    torch.save(model.state_dict(), tmp_path / "best.pth")
+    back = torch.load(tmp_path / "best.pth", map_location="cpu", weights_only=True)
+    O.set_seed(2); ref2 = O.build_model()
+    ref2.load_state_dict(back, strict=True)
+    for k, v in ref.state_dict().items():
+        assert torch.equal(ref2.state_dict()[k], v), k
+
+
+def test_reference_style_epoch_with_amp(pair):
+    """The reference's own loop shape (train.py:381-459): autocast fp16 + GradScaler + per-step .item()."""
+    O, _, _ = pair
+    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
+    opt = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
+    scaler = torch.amp.GradScaler("cuda", enabled=True)
+    x, y = O.synthetic_batch(4, 64, seed=11)
+    loader = [(x[:2], y[:2], ["a", "b"]), (x[2:], y[2:], ["c", "d"])]
+    l1 = vk.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
+    l2 = vk.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
+    assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1 + 0.05
+    vl, vd, vi = vk.validate(model, loader, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda")
+    assert np.isfinite(vl) and 0.0 <= vd <= 1.0 and 0.0 <= vi <= 1.0

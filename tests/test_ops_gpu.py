@@ -1,0 +1,524 @@
+"""Per-kernel parity (-m gpu): every C-ABI operator against the PyTorch CPU fp32 operator the reference
+would dispatch to (conv2d, batch_norm, max_pool2d, ... — SURVEY.md §2.2), on seeded inputs.
+fp32 kernels: tight tolerance.  bf16 kernels: inputs are pre-rounded to bf16 for the CPU reference, so
+the only differences are accumulation order and the final rounding (tolerance 2^-7 relative)."""
+import ctypes as C
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+vk = importlib.import_module("vickers-hardness-unet_amd")
+L_ = vk._lib
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def tol(dt, ref):
+    scale = ref.abs().max().item() + 1e-6
+    return (2e-5 if dt == torch.float32 else 1.2e-2) * scale
+
+
+def to_nhwc(x, dt):      # NCHW fp32 cpu -> NHWC dt cuda
+    return x.permute(0, 2, 3, 1).contiguous().to(dt).to(dev())
+
+
+def from_nhwc(t):        # NHWC cuda -> NCHW fp32 cpu
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(x, dt):
+    return x.to(dt).float()
+
+
+def mk_src(t, Cc, up=0, scale=None, shift=None, relu=0):
+    return L_.vk_src(t.data_ptr() if t is not None else None, Cc, up,
+                     scale.data_ptr() if scale is not None else None,
+                     shift.data_ptr() if shift is not None else None, relu)
+
+
+def null_src():
+    return L_.vk_src(None, 0, 0, None, None, 0)
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def conv_desc(dt, N, H, W, Ho, Wo, K, R, stride, pad, transposed, s0, s1=None):
+    return L_.vk_conv_desc(L_.dtype_code(dt), N, H, W, Ho, Wo, K, R, R, stride, pad, transposed, s0, s1 or null_src())
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ conv forward
+CONV_CASES = [
+    # name, N, H, C, K, R, stride, pad, affine
+    ("l1_3x3", 2, 24, 64, 64, 3, 1, 1, True),
+    ("l2_s2", 2, 24, 64, 128, 3, 2, 1, False),
+    ("l2_down1x1", 2, 24, 64, 128, 1, 2, 0, False),
+    ("l4_3x3", 1, 8, 512, 512, 3, 1, 1, True),
+    ("dec3_c2", 1, 40, 32, 32, 3, 1, 1, True),
+    ("dec4_c2_smallC", 1, 40, 16, 16, 3, 1, 1, True),
+    ("odd_edges", 3, 13, 32, 48, 3, 1, 1, True),
+]
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd(case, dtn):
+    dt = DT[dtn]
+    _, N, H, Cc, K, R, stride, pad, affine = case
+    Ho = (H + 2 * pad - R) // stride + 1
+    x = gen(N, Cc, H, H, seed=1)
+    w = gen(K, Cc, R, R, seed=2, scale=(2.0 / (Cc * R * R)) ** 0.5)
+    xd = to_nhwc(x, dt)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev())
+    v = rnd(x, dt)
+    sc = sh = None
+    if affine:
+        sc_c = 0.5 + torch.rand(Cc, generator=torch.Generator().manual_seed(3))
+        sh_c = gen(Cc, seed=4, scale=0.3)
+        sc, sh = sc_c.to(dev()), sh_c.to(dev())
+        v = rnd(torch.relu(v * sc_c.view(1, -1, 1, 1) + sh_c.view(1, -1, 1, 1)), dt)
+    ref = F.conv2d(v.double(), rnd(w, dt).double(), stride=stride, padding=pad).float()
+    y = torch.full((N, Ho, Ho, K), float("nan"), dtype=dt, device=dev())
+    stats = torch.zeros(2 * K, dtype=torch.float64, device=dev())
+    d = conv_desc(dt, N, H, H, Ho, Ho, K, R, stride, pad, 0, mk_src(xd, Cc, 0, sc, sh, 1 if affine else 0))
+    vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wd.data_ptr(), y.data_ptr(), None, 0, 0, stats.data_ptr(), st()))
+    torch.cuda.synchronize()
+    got = from_nhwc(y)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= tol(dt, ref), f"max err {err} vs tol {tol(dt, ref)}"
+    # BN partial sums are over the STORED (rounded) outputs
+    s = stats.cpu()
+    yy = from_nhwc(y).double()
+    assert torch.allclose(s[:K], yy.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3 * yy.abs().max().item() * yy[:, 0].numel() ** 0.5)
+    assert torch.allclose(s[K:], (yy * yy).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 64, 32, 32), (1, 8, 512, 256, 256), (1, 32, 32, 0, 16)],
+                         ids=["d3", "d0", "d4_noskip"])
+def test_conv_fwd_upsample_concat(shape, dtn):
+    """decoder conv1: nearest x2 upsample of src0 (with BN+ReLU prologue) concatenated with a skip."""
+    dt = DT[dtn]
+    N, H, Cup, Cskip, K = shape
+    lo = gen(N, Cup, H // 2, H // 2, seed=5)
+    sc_c = 0.5 + torch.rand(Cup, generator=torch.Generator().manual_seed(6))
+    sh_c = gen(Cup, seed=7, scale=0.3)
+    w = gen(K, Cup + Cskip, 3, 3, seed=9, scale=(2.0 / ((Cup + Cskip) * 9)) ** 0.5)
+    a = rnd(torch.relu(rnd(lo, dt) * sc_c.view(1, -1, 1, 1) + sh_c.view(1, -1, 1, 1)), dt)
+    v = F.interpolate(a, scale_factor=2, mode="nearest")
+    s1 = null_src()
+    skd = None
+    if Cskip:
+        sk = gen(N, Cskip, H, H, seed=8)
+        v = torch.cat([v, rnd(sk, dt)], dim=1)
+        skd = to_nhwc(sk, dt)
+        s1 = mk_src(skd, Cskip)
+    ref = F.conv2d(v.double(), rnd(w, dt).double(), padding=1).float()
+    lod = to_nhwc(lo, dt)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev())
+    scd, shd = sc_c.to(dev()), sh_c.to(dev())
+    y = torch.empty((N, H, H, K), dtype=dt, device=dev())
+    d = conv_desc(dt, N, H, H, H, H, K, 3, 1, 1, 0, mk_src(lod, Cup, 1, scd, shd, 1), s1)
+    vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wd.data_ptr(), y.data_ptr(), None, 0, 0, None, st()))
+    torch.cuda.synchronize()
+    err = (from_nhwc(y) - ref).abs().max().item()
+    assert err <= tol(dt, ref), err
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_stem_fwd(dtn):
+    dt = DT[dtn]
+    N, S = 2, 64
+    x = gen(N, 3, S, S, seed=11)
+    w = gen(64, 3, 7, 7, seed=12, scale=0.1)
+    xd = x.to(dev())
+    x4 = torch.empty((N, S, S, 4), dtype=dt, device=dev())
+    vk._lib.check(vk.lib().vk_input_transform(L_.dtype_code(dt), N, S, S, xd.data_ptr(), x4.data_ptr(), st()))
+    assert torch.equal(x4[..., :3].float().cpu(), rnd(x, dt).permute(0, 2, 3, 1))
+    assert (x4[..., 3] == 0).all()
+    wp = torch.zeros(64, 7, 8, 4)
+    wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    wpd = wp.reshape(64, 7, 32).to(dt).to(dev())
+    y = torch.empty((N, S // 2, S // 2, 64), dtype=dt, device=dev())
+    stats = torch.zeros(128, dtype=torch.float64, device=dev())
+    vk._lib.check(vk.lib().vk_stem_fwd(L_.dtype_code(dt), N, S, S, x4.data_ptr(), wpd.data_ptr(), y.data_ptr(), stats.data_ptr(), st()))
+    torch.cuda.synchronize()
+    ref = F.conv2d(rnd(x, dt).double(), rnd(w, dt).double(), stride=2, padding=3).float()
+    err = (from_nhwc(y) - ref).abs().max().item()
+    assert err <= tol(dt, ref), err
+
+
+# ------------------------------------------------------------------------------------------------ dgrad
+DGRAD_CASES = [
+    ("s1_3x3", 2, 24, 64, 64, 3, 1, 1),
+    ("s2_3x3", 2, 24, 64, 128, 3, 2, 1),
+    ("s2_1x1", 2, 24, 64, 128, 1, 2, 0),
+    ("k16", 1, 40, 32, 16, 3, 1, 1),      # reduction over 16 output channels (small-C mode)
+    ("k32", 1, 40, 128, 32, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("case", DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
+def test_conv_dgrad(case, dtn):
+    dt = DT[dtn]
+    _, N, H, Cc, K, R, stride, pad = case
+    Ho = (H + 2 * pad - R) // stride + 1
+    w = gen(K, Cc, R, R, seed=21, scale=(2.0 / (K * R * R)) ** 0.5)
+    dz = gen(N, K, Ho, Ho, seed=22)
+    xin = torch.zeros(N, Cc, H, H, dtype=torch.float64, requires_grad=True)
+    out = F.conv2d(xin, rnd(w, dt).double(), stride=stride, padding=pad)
+    out.backward(rnd(dz, dt).double())
+    ref = xin.grad.float()
+    dzd = to_nhwc(dz, dt)
+    wt = w.permute(1, 2, 3, 0).contiguous().to(dt).to(dev())     # [C][R][S][K]
+    dx = torch.full((N, H, H, Cc), float("nan"), dtype=dt, device=dev())
+    d = conv_desc(dt, N, Ho, Ho, H, H, Cc, R, stride, pad, 1, mk_src(dzd, K))
+    vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wt.data_ptr(), dx.data_ptr(), None, 0, 0, None, st()))
+    torch.cuda.synchronize()
+    got = from_nhwc(dx)
+    err = (got - ref).abs().max().item()
+    assert err <= tol(dt, ref), err
+    # accumulate flag
+    vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wt.data_ptr(), dx.data_ptr(), None, 0, 1, None, st()))
+    torch.cuda.synchronize()
+    err2 = (from_nhwc(dx) - 2 * ref).abs().max().item()
+    assert err2 <= 2.5 * tol(dt, ref), err2
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_conv_dgrad_split(dtn):
+    """concat gradient: channels [0,Cup) -> y, [Cup, Cup+Cskip) -> y1."""
+    dt = DT[dtn]
+    N, H, Cup, Cskip, K = 1, 16, 128, 64, 64
+    w = gen(K, Cup + Cskip, 3, 3, seed=31, scale=0.05)
+    dz = gen(N, K, H, H, seed=32)
+    xin = torch.zeros(N, Cup + Cskip, H, H, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, rnd(w, dt).double(), padding=1).backward(rnd(dz, dt).double())
+    ref = xin.grad.float()
+    dzd = to_nhwc(dz, dt)
+    wt = w.permute(1, 2, 3, 0).contiguous().to(dt).to(dev())
+    y0 = torch.empty((N, H, H, Cup), dtype=dt, device=dev())
+    y1 = torch.empty((N, H, H, Cskip), dtype=dt, device=dev())
+    d = conv_desc(dt, N, H, H, H, H, Cup + Cskip, 3, 1, 1, 1, mk_src(dzd, K))
+    vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wt.data_ptr(), y0.data_ptr(), y1.data_ptr(), Cup, 0, None, st()))
+    torch.cuda.synchronize()
+    assert (from_nhwc(y0) - ref[:, :Cup]).abs().max().item() <= tol(dt, ref)
+    assert (from_nhwc(y1) - ref[:, Cup:]).abs().max().item() <= tol(dt, ref)
+
+
+# ------------------------------------------------------------------------------------------------ wgrad
+WGRAD_CASES = [
+    ("l1", 2, 24, 64, 64, 3, 1, 1),
+    ("l2_s2", 2, 24, 64, 128, 3, 2, 1),
+    ("l2_1x1", 2, 24, 64, 128, 1, 2, 0),
+    ("l3", 1, 16, 256, 256, 3, 1, 1),
+    ("dec3_c2", 1, 40, 32, 32, 3, 1, 1),
+    ("dec4_c1", 1, 40, 32, 16, 3, 1, 1),
+    ("dec4_c2", 1, 40, 16, 16, 3, 1, 1),
+    ("dec3_c1", 1, 24, 128, 32, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv_wgrad(case, dtn):
+    dt = DT[dtn]
+    _, N, H, Cc, K, R, stride, pad = case
+    Ho = (H + 2 * pad - R) // stride + 1
+    x = gen(N, Cc, H, H, seed=41)
+    dz = gen(N, K, Ho, Ho, seed=42)
+    sc_c = 0.5 + torch.rand(Cc, generator=torch.Generator().manual_seed(43))
+    sh_c = gen(Cc, seed=44, scale=0.3)
+    v = rnd(torch.relu(rnd(x, dt) * sc_c.view(1, -1, 1, 1) + sh_c.view(1, -1, 1, 1)), dt)
+    wv = torch.zeros(K, Cc, R, R, dtype=torch.float64, requires_grad=True)
+    F.conv2d(v.double(), wv, stride=stride, padding=pad).backward(rnd(dz, dt).double())
+    ref = wv.grad.float()
+    xd, dzd = to_nhwc(x, dt), to_nhwc(dz, dt)
+    dw = torch.zeros(K, R, R, Cc, dtype=torch.float32, device=dev())
+    d = conv_desc(dt, N, H, H, Ho, Ho, K, R, stride, pad, 0, mk_src(xd, Cc, 0, sc_c.to(dev()), sh_c.to(dev()), 1))
+    vk._lib.check(vk.lib().vk_conv_wgrad(C.byref(d), dzd.data_ptr(), dw.data_ptr(), st()))
+    torch.cuda.synchronize()
+    got = dw.cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    t = (1e-4 if dt == torch.float32 else 2e-3) * (ref.abs().max().item() + 1e-6)
+    assert err <= t, f"{err} > {t}"
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_conv_wgrad_upsample_concat(dtn):
+    dt = DT[dtn]
+    N, H, Cup, Cskip, K = 1, 16, 128, 64, 64
+    lo = gen(N, Cup, H // 2, H // 2, seed=51)
+    sk = gen(N, Cskip, H, H, seed=52)
+    dz = gen(N, K, H, H, seed=53)
+    v = torch.cat([F.interpolate(rnd(lo, dt), scale_factor=2, mode="nearest"), rnd(sk, dt)], dim=1)
+    wv = torch.zeros(K, Cup + Cskip, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(v.double(), wv, padding=1).backward(rnd(dz, dt).double())
+    ref = wv.grad.float()
+    lod, skd, dzd = to_nhwc(lo, dt), to_nhwc(sk, dt), to_nhwc(dz, dt)
+    dw = torch.zeros(K, 3, 3, Cup + Cskip, dtype=torch.float32, device=dev())
+    d = conv_desc(dt, N, H, H, H, H, K, 3, 1, 1, 0, mk_src(lod, Cup, 1), mk_src(skd, Cskip))
+    vk._lib.check(vk.lib().vk_conv_wgrad(C.byref(d), dzd.data_ptr(), dw.data_ptr(), st()))
+    torch.cuda.synchronize()
+    err = (dw.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= (1e-4 if dt == torch.float32 else 2e-3) * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_stem_wgrad(dtn):
+    dt = DT[dtn]
+    N, S = 2, 64
+    x = gen(N, 3, S, S, seed=61)
+    dz = gen(N, 64, S // 2, S // 2, seed=62)
+    wv = torch.zeros(64, 3, 7, 7, dtype=torch.float64, requires_grad=True)
+    F.conv2d(rnd(x, dt).double(), wv, stride=2, padding=3).backward(rnd(dz, dt).double())
+    ref = wv.grad.float()
+    x4 = torch.zeros((N, S, S, 4), dtype=dt, device=dev())
+    x4[..., :3] = x.permute(0, 2, 3, 1).to(dt).to(dev())
+    dzd = to_nhwc(dz, dt)
+    dw = torch.zeros(64, 7, 7, 3, dtype=torch.float32, device=dev())
+    vk._lib.check(vk.lib().vk_stem_wgrad(L_.dtype_code(dt), N, S, S, x4.data_ptr(), dzd.data_ptr(), dw.data_ptr(), st()))
+    torch.cuda.synchronize()
+    err = (dw.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= (1e-4 if dt == torch.float32 else 2e-3) * ref.abs().max().item(), err
+
+
+# ------------------------------------------------------------------------------------------------ BN / pool / tails
+def test_bn_finalize_train_and_eval():
+    Cc, cnt = 64, 1000.0
+    g = torch.Generator().manual_seed(71)
+    data = torch.randn(1000, Cc, generator=g, dtype=torch.float64) * 2 + 0.5
+    stats = torch.cat([data.sum(0), (data * data).sum(0)]).to(dev())
+    gamma = (0.5 + torch.rand(Cc, generator=g)).to(dev())
+    beta = torch.randn(Cc, generator=g).to(dev())
+    rm, rv = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())
+    scale, shift, mean, invstd = (torch.empty(Cc, device=dev()) for _ in range(4))
+    vk._lib.check(vk.lib().vk_bn_finalize(Cc, 1, stats.data_ptr(), cnt, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
+                                          rv.data_ptr(), 1e-5, 0.1, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                          invstd.data_ptr(), st()))
+    bn = torch.nn.BatchNorm1d(Cc).double()
+    bn.weight.data = gamma.cpu().double(); bn.bias.data = beta.cpu().double()
+    bn.train()
+    ref = bn(data)
+    got = data * scale.cpu().double() + shift.cpu().double()
+    assert torch.allclose(got, ref, atol=1e-5)
+    assert torch.allclose(rm.cpu().double(), bn.running_mean, atol=1e-6)
+    assert torch.allclose(rv.cpu().double(), bn.running_var, atol=1e-5)
+    # eval
+    vk._lib.check(vk.lib().vk_bn_finalize(Cc, 0, None, 0.0, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                          1e-5, 0.1, scale.data_ptr(), shift.data_ptr(), None, None, st()))
+    bn.eval()
+    assert torch.allclose(data * scale.cpu().double() + shift.cpu().double(), bn(data), atol=1e-5)
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_bn_relu_maxpool_and_bwd(dtn):
+    dt = DT[dtn]
+    N, H, Cc = 2, 16, 64
+    z = gen(N, Cc, H, H, seed=81)
+    sc_c = 0.5 + torch.rand(Cc, generator=torch.Generator().manual_seed(82))
+    sh_c = gen(Cc, seed=83, scale=0.3)
+    zd = to_nhwc(z, dt)
+    pooled = torch.empty((N, H // 2, H // 2, Cc), dtype=dt, device=dev())
+    am = torch.empty((N, H // 2, H // 2, Cc), dtype=torch.uint8, device=dev())
+    vk._lib.check(vk.lib().vk_bn_relu_maxpool(L_.dtype_code(dt), N, H, H, Cc, zd.data_ptr(), sc_c.to(dev()).data_ptr(),
+                                              sh_c.to(dev()).data_ptr(), pooled.data_ptr(), am.data_ptr(), st()))
+    a = torch.relu(rnd(z, dt) * sc_c.view(1, -1, 1, 1) + sh_c.view(1, -1, 1, 1)).requires_grad_(True)
+    ref = F.max_pool2d(a, 3, 2, 1)
+    assert (from_nhwc(pooled) - ref.detach()).abs().max().item() <= tol(dt, ref.detach())
+    # backward: dy starts as the skip gradient, pool gradient is added
+    dp = gen(N, Cc, H // 2, H // 2, seed=84)
+    base = gen(N, Cc, H, H, seed=85)
+    ref.backward(rnd(dp, dt))
+    want = rnd(base, dt) + a.grad
+    dy = to_nhwc(base, dt)
+    vk._lib.check(vk.lib().vk_maxpool_bwd(L_.dtype_code(dt), N, H, H, Cc, to_nhwc(dp, dt).data_ptr(), am.data_ptr(), dy.data_ptr(), st()))
+    torch.cuda.synchronize()
+    assert (from_nhwc(dy) - want).abs().max().item() <= tol(dt, want) * 2
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("down", [False, True])
+def test_bn_add_relu(dtn, down):
+    dt = DT[dtn]
+    N, H, Cc = 2, 8, 128
+    z, r = gen(N, Cc, H, H, seed=91), gen(N, Cc, H, H, seed=92)
+    g = torch.Generator().manual_seed(93)
+    sc, sh, rsc, rsh = (torch.rand(Cc, generator=g) + 0.5 for _ in range(4))
+    v = lambda t: t.view(1, -1, 1, 1)
+    res = rnd(r, dt) * v(rsc) + v(rsh) if down else rnd(r, dt)
+    ref = torch.relu(rnd(z, dt) * v(sc) + v(sh) + res)
+    out = torch.empty((N, H, H, Cc), dtype=dt, device=dev())
+    scd, shd, rscd, rshd = (t.to(dev()) for t in (sc, sh, rsc, rsh))
+    vk._lib.check(vk.lib().vk_bn_add_relu(L_.dtype_code(dt), N * H * H, Cc, to_nhwc(z, dt).data_ptr(), scd.data_ptr(), shd.data_ptr(),
+                                          to_nhwc(r, dt).data_ptr(), rscd.data_ptr() if down else None,
+                                          rshd.data_ptr() if down else None, out.data_ptr(), st()))
+    torch.cuda.synchronize()
+    assert (from_nhwc(out) - ref).abs().max().item() <= tol(dt, ref)
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("mask_mode", [1, 2])
+def test_bn_relu_backward(dtn, mask_mode):
+    """BatchNorm(train)+ReLU backward against autograd of F.batch_norm + relu (mask from own output) or
+    + residual relu (mask from the block output)."""
+    dt = DT[dtn]
+    N, H, Cc = 2, 12, 64
+    z = rnd(gen(N, Cc, H, H, seed=101), dt)
+    dy = rnd(gen(N, Cc, H, H, seed=102), dt)
+    res = rnd(gen(N, Cc, H, H, seed=103), dt)
+    g = torch.Generator().manual_seed(104)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.2
+    zr = z.clone().double().requires_grad_(True)
+    gam = gamma.clone().double().requires_grad_(True)
+    bet = beta.clone().double().requires_grad_(True)
+    bn = F.batch_norm(zr, None, None, gam, bet, training=True, eps=1e-5)
+    out = torch.relu(bn) if mask_mode == 1 else torch.relu(bn + res.double())
+    out.backward(dy.double())
+    cnt = float(N * H * H)
+    mean = z.double().mean(dim=(0, 2, 3))
+    var = z.double().var(dim=(0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = (gamma.double() * invstd).float().to(dev())
+    shift = (beta.double() - mean * gamma.double() * invstd).float().to(dev())
+    sums = torch.zeros(2 * Cc, dtype=torch.float64, device=dev())
+    zd, dyd = to_nhwc(z, dt), to_nhwc(dy, dt)
+    outd = to_nhwc(out.detach().float(), dt)
+    code = L_.dtype_code(dt)
+    vk._lib.check(vk.lib().vk_bn_bwd_reduce(code, N * H * H, Cc, dyd.data_ptr(), zd.data_ptr(), mask_mode, scale.data_ptr(),
+                                            shift.data_ptr(), outd.data_ptr(), sums.data_ptr(), st()))
+    dgam, dbet = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
+    coef = torch.empty(3 * Cc, device=dev())
+    vk._lib.check(vk.lib().vk_bn_bwd_coeffs(Cc, sums.data_ptr(), cnt, gamma.to(dev()).data_ptr(), mean.float().to(dev()).data_ptr(),
+                                            invstd.float().to(dev()).data_ptr(), dgam.data_ptr(), dbet.data_ptr(), coef.data_ptr(), st()))
+    dz = torch.empty_like(zd)
+    gout = torch.zeros_like(zd)
+    vk._lib.check(vk.lib().vk_bn_bwd_apply(code, N * H * H, Cc, dyd.data_ptr(), zd.data_ptr(), mask_mode, scale.data_ptr(),
+                                           shift.data_ptr(), outd.data_ptr(), coef.data_ptr(), dz.data_ptr(), gout.data_ptr(), 0, st()))
+    torch.cuda.synchronize()
+    rt = 1e-4 if dt == torch.float32 else 2e-2
+    assert (dgam.cpu() - gam.grad.float()).abs().max().item() <= rt * gam.grad.abs().max().item() + 1e-4
+    assert (dbet.cpu() - bet.grad.float()).abs().max().item() <= rt * bet.grad.abs().max().item() + 1e-4
+    ref = zr.grad.float()
+    assert (from_nhwc(dz) - ref).abs().max().item() <= (2e-4 if dt == torch.float32 else 2e-2) * ref.abs().max().item()
+    gref = dy * (out.detach().float() > 0)
+    assert (from_nhwc(gout) - gref).abs().max().item() <= tol(dt, gref)
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_upsample_bwd(dtn):
+    dt = DT[dtn]
+    N, H, Cc = 2, 16, 32
+    d_up = rnd(gen(N, Cc, H, H, seed=111), dt)
+    lo = torch.zeros(N, Cc, H // 2, H // 2, requires_grad=True)
+    F.interpolate(lo, scale_factor=2, mode="nearest").backward(d_up)
+    out = torch.empty((N, H // 2, H // 2, Cc), dtype=dt, device=dev())
+    vk._lib.check(vk.lib().vk_upsample2x_bwd(L_.dtype_code(dt), N, H, H, Cc, to_nhwc(d_up, dt).data_ptr(), out.data_ptr(), 0, st()))
+    torch.cuda.synchronize()
+    assert (from_nhwc(out) - lo.grad).abs().max().item() <= tol(dt, lo.grad)
+
+
+# ------------------------------------------------------------------------------------------------ head / loss / optimizer
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_head_fwd_bwd(dtn):
+    dt = DT[dtn]
+    N, H = 2, 24
+    z = rnd(gen(N, 16, H, H, seed=121), dt)
+    g = torch.Generator().manual_seed(122)
+    sc, sh = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.3
+    w = gen(1, 16, 3, 3, seed=123, scale=0.2)
+    b = torch.tensor([0.37])
+    a = torch.relu(z * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).double().requires_grad_(True)
+    wv = w.clone().double().requires_grad_(True)
+    bv = b.clone().double().requires_grad_(True)
+    ref = F.conv2d(a, wv, bv, padding=1)
+    dl = gen(N, 1, H, H, seed=124)
+    ref.backward(dl.double())
+    zd = to_nhwc(z, dt)
+    w9 = w[0].permute(1, 2, 0).contiguous().to(dev())       # [3][3][16]
+    src = mk_src(zd, 16, 0, sc.to(dev()), sh.to(dev()), 1)
+    logits = torch.empty(N, 1, H, H, device=dev())
+    bd = b.to(dev())
+    vk._lib.check(vk.lib().vk_head_fwd(L_.dtype_code(dt), N, H, H, C.byref(src), w9.data_ptr(), bd.data_ptr(), logits.data_ptr(), st()))
+    torch.cuda.synchronize()
+    assert (logits.cpu() - ref.detach().float()).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    dy = torch.empty((N, H, H, 16), dtype=dt, device=dev())
+    dw = torch.zeros(3, 3, 16, device=dev())
+    db = torch.zeros(1, device=dev())
+    vk._lib.check(vk.lib().vk_head_bwd(L_.dtype_code(dt), N, H, H, C.byref(src), w9.data_ptr(), dl.to(dev()).data_ptr(), dy.data_ptr(),
+                                       dw.data_ptr(), db.data_ptr(), st()))
+    torch.cuda.synchronize()
+    assert (from_nhwc(dy) - a.grad.float()).abs().max().item() <= tol(dt, a.grad.float())
+    assert (dw.cpu().permute(2, 0, 1) - wv.grad[0].float()).abs().max().item() <= 1e-3 * wv.grad.abs().max().item()
+    assert abs(db.item() - bv.grad.item()) <= 1e-3 * abs(bv.grad.item()) + 1e-4
+
+
+@pytest.mark.parametrize("wb,wd", [(1.0, 1.0), (0.0, 1.0), (1.0, 0.0)])
+def test_bce_dice_loss(wb, wd):
+    from oracle import unet_oracle as O
+    g = torch.Generator().manual_seed(131)
+    x = (torch.randn(3, 1, 32, 32, generator=g) * 3).requires_grad_(True)
+    y = (torch.rand(3, 1, 32, 32, generator=g) > 0.8).float()
+    ref = wb * F.binary_cross_entropy_with_logits(x, y) + wd * O.DiceLoss()(x, y)
+    ref.backward()
+    xd, yd = x.detach().to(dev()), y.to(dev())
+    sums = torch.empty(8, dtype=torch.float64, device=dev())
+    out = torch.empty(4, device=dev())
+    dl = torch.empty_like(xd)
+    vk._lib.check(vk.lib().vk_bce_dice_loss(x.numel(), xd.data_ptr(), yd.data_ptr(), sums.data_ptr(), out.data_ptr(), dl.data_ptr(),
+                                            2.0, wb, wd, st()))
+    torch.cuda.synchronize()
+    assert out[0].item() == pytest.approx(ref.item(), rel=1e-5, abs=1e-6)
+    assert (dl.cpu() / 2.0 - x.grad).abs().max().item() <= 1e-5 * x.grad.abs().max().item() + 1e-9
+    # empty target => Dice term masked to zero (smp semantics)
+    yz = torch.zeros_like(yd)
+    vk._lib.check(vk.lib().vk_bce_dice_loss(x.numel(), xd.data_ptr(), yz.data_ptr(), sums.data_ptr(), out.data_ptr(), None, 1.0, 0.0, 1.0, st()))
+    torch.cuda.synchronize()
+    assert out[0].item() == 0.0
+
+
+def test_adamw_matches_torch():
+    n = 10007
+    g = torch.Generator().manual_seed(141)
+    p0 = torch.randn(n, generator=g)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=5e-5, weight_decay=1e-4)
+    pd = p0.clone().to(dev())
+    m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        gd = gr.to(dev())
+        vk._lib.check(vk.lib().vk_adamw_step(n, pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), 5e-5, 0.9, 0.999, 1e-8, 1e-4,
+                                             step, 1.0, None, None, 0, st()))
+    torch.cuda.synchronize()
+    assert (pd.cpu() - pr.detach()).abs().max().item() <= 2e-7
+    # found_inf skips the step
+    before = pd.clone()
+    fi = torch.ones(1, dtype=torch.int32, device=dev())
+    vk._lib.check(vk.lib().vk_adamw_step(n, pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), 5e-5, 0.9, 0.999, 1e-8, 1e-4,
+                                         4, 1.0, fi.data_ptr(), None, 0, st()))
+    torch.cuda.synchronize()
+    assert torch.equal(before, pd)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev())
+    gd[17] = float("inf")
+    vk._lib.check(vk.lib().vk_amp_check_inf(n, gd.data_ptr(), bad.data_ptr(), st()))
+    torch.cuda.synchronize()
+    assert bad.item() == 1

@@ -1,0 +1,24 @@
+"""vickers-hardness-unet_amd — MI355X (gfx950) implementation of the one compute path of
+ZooMEISTER/vickers-hardness-Unet: the ResNet-34 U-Net forward / BCE+Dice / backward / AdamW step.
+
+Import by string (the directory name carries hyphens)::
+
+    import importlib
+    vk = importlib.import_module("vickers-hardness-unet_amd")
+    model = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).cuda()
+    loss_dice = vk.losses.DiceLoss(mode="binary")
+    optimizer = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
+
+Everything heavy runs in libvkunet.so (hand-written HIP); there is no CPU fallback."""
+from . import _lib, losses, metrics, parallel  # noqa: F401
+from ._lib import VkError, build, lib  # noqa: F401
+from .losses import BCEDiceLoss, DiceLoss  # noqa: F401
+from .metrics import dice_coef, iou_coef  # noqa: F401
+from .optim import FusedAdamW, adamw_for  # noqa: F401
+from .parallel import GradientReducer, broadcast_model, make_data_parallel  # noqa: F401
+from .train import train_one_epoch, validate  # noqa: F401
+from .unet import Unet, build_model  # noqa: F401
+
+__all__ = ["Unet", "build_model", "DiceLoss", "BCEDiceLoss", "FusedAdamW", "adamw_for", "GradientReducer",
+           "make_data_parallel", "broadcast_model", "dice_coef", "iou_coef", "train_one_epoch", "validate",
+           "VkError", "build", "lib", "losses", "metrics", "parallel"]

@@ -1,0 +1,402 @@
+// Weight gradient of the convolutions (replaces ATen conv backward-weight behind loss.backward(),
+// reference train.py:443/:448):
+//
+//   dW[k][tap][c] += sum_{pixels m in this split}  dz[m][k] * V[m @ tap][c]
+//
+// A GEMM whose reduction runs over pixels.  Both operands are pixel-major in HBM (NHWC), i.e.
+// "K-strided" for the MFMA; they are staged as they lie ([pixel][channel], 16-byte vectors, BN+ReLU /
+// upsample / concat applied to V on the way) and the transposition happens in the LDS read:
+//   16-bit : ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, two reads per fragment)
+//   fp32   : ds_read_b32, lane = (channel, pixel-in-group) — already the 16x16x4 operand layout.
+// Split-K over pixel ranges (grid.z) with fp32 atomics into the flat gradient buffer.
+// Two wave layouts: big tiles split the output tile over the 4 waves; small-channel layers
+// (K or C <= 32: decoder blocks 3/4, stem) give every wave the whole tile on its own 32-pixel slice.
+#include "vk_common.h"
+
+namespace vk {
+
+struct SrcDevW {
+  const void* ptr;
+  const float* scale;
+  const float* shift;
+  int C, up, relu;
+  uint32_t bytes;
+};
+
+struct WgradParams {
+  SrcDevW s0, s1;
+  const void* dz;
+  uint32_t dz_bytes;
+  float* dw;
+  int N, H, W, Ho, Wo, K, R, S, slog, pad;
+  int C, M, RS, mps, ctiles, stem;
+  FastDiv div_hw, div_w, div_ct, div_s;
+};
+
+template <typename T, int BMW, int BNW, bool WSPLIT>
+struct WgradCfg {
+  using Tr = ElemTraits<T>;
+  static constexpr int VE = Tr::kVec;
+  static constexpr int EB = Tr::kBytes;
+  static constexpr int PX = WSPLIT ? 128 : 32;                 // pixels per chunk
+  static constexpr int ZV = BMW / VE, VV = BNW / VE;            // vectors per pixel row
+  static constexpr int ZPASS = (PX * ZV + 255) / 256, VPASS = (PX * VV + 255) / 256;
+  // row pads chosen so that the transposed / b32 fragment reads are bank-conflict free
+  static constexpr int zpad(int ch) { return EB == 2 ? (((ch * 2 / 32) % 2 == 0) ? 32 : 0) : ((ch % 32 == 0) ? 64 : 0); }
+  static constexpr int ZSB = BMW * EB + zpad(BMW);
+  static constexpr int VSB = BNW * EB + zpad(BNW);
+  static constexpr int STAGE = PX * (ZSB + VSB);
+  static constexpr int WGK = WSPLIT ? 1 : 2, WGC = WSPLIT ? 1 : 2;
+  static constexpr int WK = BMW / WGK, WC = BNW / WGC;
+  static constexpr int TK = WK / 16, TCc = WC / 16;
+  static constexpr int SMEM = 2 * STAGE;
+  static_assert(TK >= 1 && TCc >= 1, "tile too small");
+};
+
+template <typename T, int BMW, int BNW, bool WSPLIT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+  using Cfg = WgradCfg<T, BMW, BNW, WSPLIT>;
+  constexpr int VE = Cfg::VE, EB = Cfg::EB, PX = Cfg::PX, ZV = Cfg::ZV, VV = Cfg::VV;
+  constexpr int ZPASS = Cfg::ZPASS, VPASS = Cfg::VPASS, ZSB = Cfg::ZSB, VSB = Cfg::VSB, STAGE = Cfg::STAGE;
+  constexpr int TK = Cfg::TK, TCc = Cfg::TCc;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = blockIdx.x * BMW;
+  const int tap = (int)fdiv(blockIdx.y, p.div_ct);
+  const int ct = blockIdx.y - tap * p.ctiles;
+  const int c0 = ct * BNW;                       // channel in concat space
+  const int r = (int)fdiv((uint32_t)tap, p.div_s), s = tap - r * p.S;
+  const int mbeg = blockIdx.z * p.mps;
+  const int mend = min(p.M, mbeg + p.mps);
+  const int nch = (mend - mbeg + PX - 1) / PX;
+  if (nch <= 0) return;
+
+  const bool first = c0 < p.s0.C;
+  const SrcDevW& sd = first ? p.s0 : p.s1;
+  const int cl0 = first ? c0 : c0 - p.s0.C;
+  const __amdgpu_buffer_rsrc_t rsv = make_rsrc(sd.ptr, sd.bytes);
+  const __amdgpu_buffer_rsrc_t rsz = make_rsrc(p.dz, p.dz_bytes);
+  const int up = sd.up;
+  const int Hs = p.H >> up, Ws = p.W >> up;
+  const int HoWo = p.Ho * p.Wo;
+  const bool affine = sd.scale != nullptr;
+  const bool relu = sd.relu != 0;
+
+  // V-vector channel of this thread is fixed for the whole kernel -> scale/shift loaded once
+  float sc[VPASS][VE], sh[VPASS][VE];
+#pragma unroll
+  for (int i = 0; i < VPASS; ++i) {
+    const int v = tid + i * 256;
+    const int vec = v % VV;
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { sc[i][j] = 1.f; sh[i][j] = 0.f; }
+    if (affine && v < PX * VV) {
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        sc[i][j] = sd.scale[cl0 + vec * VE + j];
+        sh[i][j] = sd.shift[cl0 + vec * VE + j];
+      }
+    }
+  }
+
+  u32x4_t zreg[ZPASS], vreg[VPASS];
+  uint32_t vmask = 0;
+
+  auto load_chunk = [&](int ch) {
+    const int mb = mbeg + ch * PX;
+#pragma unroll
+    for (int i = 0; i < ZPASS; ++i) {
+      const int v = tid + i * 256;
+      const int px = v / ZV, vec = v % ZV;
+      const int m = mb + px;
+      const bool ok = (v < PX * ZV) && (m < mend) && (k0 + vec * VE < p.K);
+      const uint32_t off = (uint32_t)(m * p.K + k0 + vec * VE) * (uint32_t)EB;
+      zreg[i] = buf_load16(rsz, ok ? off : kOOB);
+    }
+    vmask = 0;
+#pragma unroll
+    for (int i = 0; i < VPASS; ++i) {
+      const int v = tid + i * 256;
+      const int px = v / VV, vec = v % VV;
+      const int m = mb + px;
+      bool ok = (v < PX * VV) && (m < mend);
+      const int n = (int)fdiv((uint32_t)m, p.div_hw);
+      const int rem = m - n * HoWo;
+      const int pp = (int)fdiv((uint32_t)rem, p.div_w);
+      const int q = rem - pp * p.Wo;
+      uint32_t off;
+      if (!p.stem) {
+        const int h = (pp << p.slog) - p.pad + r;
+        const int w = (q << p.slog) - p.pad + s;
+        ok = ok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        off = (uint32_t)(((n * Hs + (h >> up)) * Ws + (w >> up)) * sd.C + cl0 + vec * VE) * (uint32_t)EB;
+        vreg[i] = buf_load16(rsv, ok ? off : kOOB);
+      } else {
+        // stem: "tap" = filter row, "channels" = 8 pixels x 4 channels along W
+        constexpr int PPV = VE / 4;
+        const int h = 2 * pp - 3 + tap;
+        const int wb = 2 * q - 3 + vec * PPV;
+        const bool okh = ok && (unsigned)h < (unsigned)p.H;
+        const uint32_t rowoff = (uint32_t)((n * p.H + h) * p.W) * 4u * (uint32_t)EB;
+        if (PPV == 1) {
+          const bool o0 = okh && (unsigned)wb < (unsigned)p.W;
+          vreg[i] = buf_load16(rsv, o0 ? rowoff + (uint32_t)wb * 4u * EB : kOOB);
+        } else {
+          const bool o0 = okh && (unsigned)wb < (unsigned)p.W;
+          const bool o1 = okh && (unsigned)(wb + 1) < (unsigned)p.W;
+          const u32x2_t lo = __builtin_amdgcn_raw_buffer_load_b64(rsv, o0 ? rowoff + (uint32_t)wb * 4u * EB : kOOB, 0, 0);
+          const u32x2_t hi = __builtin_amdgcn_raw_buffer_load_b64(rsv, o1 ? rowoff + (uint32_t)(wb + 1) * 4u * EB : kOOB, 0, 0);
+          vreg[i] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+        }
+      }
+      vmask |= (ok ? 1u : 0u) << i;
+    }
+  };
+
+  auto store_chunk = [&](int stage) {
+    char* Zs = smem + stage * STAGE;
+    char* Vs = Zs + PX * ZSB;
+#pragma unroll
+    for (int i = 0; i < ZPASS; ++i) {
+      const int v = tid + i * 256;
+      if (v < PX * ZV) *reinterpret_cast<u32x4_t*>(Zs + (v / ZV) * ZSB + (v % ZV) * 16) = zreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPASS; ++i) {
+      const int v = tid + i * 256;
+      u32x4_t x = vreg[i];
+      if (affine) {
+        float f[VE];
+        Vec16<T>::unpack(x, f);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+          f[j] = fmaf(f[j], sc[i][j], sh[i][j]);
+          if (relu) f[j] = fmaxf(f[j], 0.f);
+        }
+        x = Vec16<T>::pack(f);
+        if (!((vmask >> i) & 1u)) x = u32x4_t{0, 0, 0, 0};
+      }
+      if (v < PX * VV) *reinterpret_cast<u32x4_t*>(Vs + (v / VV) * VSB + (v % VV) * 16) = x;
+    }
+  };
+
+  const int wk0 = WSPLIT ? 0 : (wave >> 1) * Cfg::WK;
+  const int wc0 = WSPLIT ? 0 : (wave & 1) * Cfg::WC;
+  const int wpx = WSPLIT ? wave * 32 : 0;        // this wave's pixel slice inside the chunk
+  f32x4_t acc[TK][TCc];
+#pragma unroll
+  for (int a = 0; a < TK; ++a)
+#pragma unroll
+    for (int b = 0; b < TCc; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int stage) {
+    const char* Zs = smem + stage * STAGE + wpx * ZSB;
+    const char* Vs = smem + stage * STAGE + PX * ZSB + wpx * VSB;
+    if (EB == 2) {
+      // lane j of 16-lane group g supplies row (pixel) 4g + (j>>2) [+16 for the second read], columns 4*(j&3)..+3
+      const int g = lane >> 4, j = lane & 15;
+      const int prow = 4 * g + (j >> 2);
+      const int cofs = 4 * (j & 3) * 2;
+      u32x4_t zf[TK], vf[TCc];
+      typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+#pragma unroll
+      for (int a = 0; a < TK; ++a) {
+        const char* b0 = Zs + prow * ZSB + (wk0 + a * 16) * 2 + cofs;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + 16 * ZSB));
+        const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+        zf[a] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+      }
+#pragma unroll
+      for (int b = 0; b < TCc; ++b) {
+        const char* b0 = Vs + prow * VSB + (wc0 + b * 16) * 2 + cofs;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + 16 * VSB));
+        const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+        vf[b] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+      }
+#pragma unroll
+      for (int a = 0; a < TK; ++a)
+#pragma unroll
+        for (int b = 0; b < TCc; ++b) acc[a][b] = Mma<T>::run(zf[a], vf[b], acc[a][b]);
+    } else {
+      const int i = lane & 15, kg = lane >> 4;
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        float zf[TK], vf[TCc];
+#pragma unroll
+        for (int a = 0; a < TK; ++a)
+          zf[a] = *reinterpret_cast<const float*>(Zs + (4 * st + kg) * ZSB + (wk0 + a * 16 + i) * 4);
+#pragma unroll
+        for (int b = 0; b < TCc; ++b)
+          vf[b] = *reinterpret_cast<const float*>(Vs + (4 * st + kg) * VSB + (wc0 + b * 16 + i) * 4);
+#pragma unroll
+        for (int a = 0; a < TK; ++a)
+#pragma unroll
+          for (int b = 0; b < TCc; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[a], vf[b], acc[a][b], 0, 0, 0);
+      }
+    }
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const bool more = ch + 1 < nch;
+    if (more) load_chunk(ch + 1);
+    compute(ch & 1);
+    if (more) store_chunk((ch + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: fp32 atomics into dW[k][tap][c] (stem: [k][r][s][3], padding columns dropped) ----
+#pragma unroll
+  for (int a = 0; a < TK; ++a)
+#pragma unroll
+    for (int b = 0; b < TCc; ++b) {
+      const int cc = c0 + wc0 + b * 16 + (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = k0 + wk0 + a * 16 + (lane >> 4) * 4 + e;
+        if (k >= p.K) continue;
+        if (!p.stem) {
+          if (cc < p.C) atomicAdd(p.dw + ((size_t)k * p.RS + tap) * p.C + cc, acc[a][b][e]);
+        } else {
+          const int sx = cc >> 2, ci = cc & 3;
+          if (sx < 7 && ci < 3) atomicAdd(p.dw + (((size_t)k * 7 + tap) * 7 + sx) * 3 + ci, acc[a][b][e]);
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+template <typename T, int BMW, int BNW, bool WSPLIT>
+static int launch_w(WgradParams p, hipStream_t st) {
+  using Cfg = WgradCfg<T, BMW, BNW, WSPLIT>;
+  p.ctiles = (p.C + BNW - 1) / BNW;
+  p.div_ct = vkh::make_fastdiv((uint32_t)p.ctiles);
+  const int ktiles = (p.K + BMW - 1) / BMW;
+  const int out_tiles = ktiles * p.ctiles * p.RS;
+  // split the pixel reduction so that ~4 workgroups per CU exist, each with at least 8 chunks
+  int chunks = (p.M + Cfg::PX - 1) / Cfg::PX;
+  int splits = (1024 + out_tiles - 1) / out_tiles;
+  if (splits > chunks / 8) splits = chunks / 8;
+  if (splits < 1) splits = 1;
+  int cps = (chunks + splits - 1) / splits;
+  p.mps = cps * Cfg::PX;
+  splits = (p.M + p.mps - 1) / p.mps;
+  dim3 grid(ktiles, p.ctiles * p.RS, splits);
+  static bool attr_done = false;
+  if (!attr_done && Cfg::SMEM > 64 * 1024) {
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, BMW, BNW, WSPLIT>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW, WSPLIT>), grid, dim3(256), Cfg::SMEM, st, p);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+template <typename T>
+static int launch_w_shape(const WgradParams& p, int cmin, hipStream_t st) {
+  // cmin = smallest per-source channel count (a c-tile must not straddle the concat boundary)
+  if (p.K >= 128 && cmin % 128 == 0) return launch_w<T, 128, 128, false>(p, st);
+  if (p.K >= 64 && cmin % 64 == 0) return launch_w<T, 64, 64, false>(p, st);
+  if (p.K >= 64 && cmin % 32 == 0) return launch_w<T, 64, 32, true>(p, st);
+  if (p.K >= 32 && cmin % 64 == 0) return launch_w<T, 32, 64, true>(p, st);
+  if (p.K >= 32 && cmin % 32 == 0) return launch_w<T, 32, 32, true>(p, st);
+  if (cmin % 32 == 0) return launch_w<T, 16, 32, true>(p, st);
+  return launch_w<T, 16, 16, true>(p, st);
+}
+
+static int dispatch_w(vk_dtype dt, const WgradParams& p, int cmin, hipStream_t st) {
+  switch (dt) {
+    case VK_F32: return launch_w_shape<float>(p, cmin, st);
+    case VK_BF16: return launch_w_shape<bf16_t>(p, cmin, st);
+    case VK_F16: return launch_w_shape<f16_t>(p, cmin, st);
+  }
+  vkh::set_error("bad dtype %d", (int)dt);
+  return VK_ERR_ARG;
+}
+
+static SrcDevW make_srcw(const vk_src& s, int N, int H, int W, int eb) {
+  SrcDevW d;
+  d.ptr = s.ptr; d.scale = s.scale; d.shift = s.shift; d.C = s.C; d.up = s.up; d.relu = s.relu;
+  d.bytes = s.ptr ? (uint32_t)((size_t)N * (H >> s.up) * (W >> s.up) * s.C * eb) : 0u;
+  return d;
+}
+
+int conv_wgrad_impl(const vk_conv_desc* d, const void* dz, float* dw, hipStream_t st) {
+  VK_CHECK_ARG(d && dz && dw && d->src0.ptr, "vk_conv_wgrad: null argument");
+  VK_CHECK_ARG(!d->transposed, "vk_conv_wgrad: descriptor must describe the forward convolution");
+  const int eb = d->dtype == VK_F32 ? 4 : 2;
+  const int C = d->src0.C + (d->src1.ptr ? d->src1.C : 0);
+  VK_CHECK_ARG(d->K % 16 == 0 && C % 16 == 0, "vk_conv_wgrad: K=%d, C=%d must be multiples of 16", d->K, C);
+  VK_CHECK_ARG(d->stride == 1 || d->stride == 2, "vk_conv_wgrad: stride %d unsupported", d->stride);
+  const size_t in_bytes = (size_t)d->N * d->H * d->W * C * eb, dz_bytes = (size_t)d->N * d->Ho * d->Wo * d->K * eb;
+  VK_CHECK_ARG(in_bytes < (1ull << 31) && dz_bytes < (1ull << 31), "vk_conv_wgrad: tensor too large for 32-bit offsets");
+  WgradParams p;
+  p.s0 = make_srcw(d->src0, d->N, d->H, d->W, eb);
+  if (d->src1.ptr) p.s1 = make_srcw(d->src1, d->N, d->H, d->W, eb);
+  else p.s1 = SrcDevW{nullptr, nullptr, nullptr, 0, 0, 0, 0u};
+  p.dz = dz;
+  p.dz_bytes = (uint32_t)dz_bytes;
+  p.dw = dw;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.K = d->K; p.R = d->R; p.S = d->S;
+  p.slog = d->stride == 2 ? 1 : 0;
+  p.pad = d->pad;
+  p.C = C;
+  p.M = d->N * d->Ho * d->Wo;
+  p.RS = d->R * d->S;
+  p.stem = 0;
+  p.div_hw = vkh::make_fastdiv((uint32_t)(d->Ho * d->Wo));
+  p.div_w = vkh::make_fastdiv((uint32_t)d->Wo);
+  p.div_s = vkh::make_fastdiv((uint32_t)d->S);
+  int cmin = d->src0.C;
+  if (d->src1.ptr && d->src1.C < cmin) cmin = d->src1.C;
+  if (d->src1.ptr) {
+    // tiles must not straddle the concat boundary: use the gcd-like granularity of both sources
+    int g = 128;
+    while (g > 16 && (d->src0.C % g || d->src1.C % g)) g >>= 1;
+    cmin = g;
+  }
+  return dispatch_w(d->dtype, p, cmin, st);
+}
+
+int stem_wgrad_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void* dz, float* dw, hipStream_t st) {
+  VK_CHECK_ARG(x4 && dz && dw, "vk_stem_wgrad: null argument");
+  const int eb = dt == VK_F32 ? 4 : 2;
+  WgradParams p;
+  p.s0 = SrcDevW{x4, nullptr, nullptr, 4, 0, 0, (uint32_t)((size_t)N * H * W * 4 * eb)};
+  p.s1 = SrcDevW{nullptr, nullptr, nullptr, 0, 0, 0, 0u};
+  p.dz = dz;
+  p.dz_bytes = (uint32_t)((size_t)N * (H / 2) * (W / 2) * 64 * eb);
+  p.dw = dw;
+  p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2; p.K = 64; p.R = 7; p.S = 1;
+  p.slog = 1; p.pad = 3;
+  p.C = 32;
+  p.M = N * p.Ho * p.Wo;
+  p.RS = 7;
+  p.stem = 1;
+  p.div_hw = vkh::make_fastdiv((uint32_t)(p.Ho * p.Wo));
+  p.div_w = vkh::make_fastdiv((uint32_t)p.Wo);
+  p.div_s = vkh::make_fastdiv(1);
+  switch (dt) {
+    case VK_F32: return launch_w<float, 64, 32, true>(p, st);
+    case VK_BF16: return launch_w<bf16_t, 64, 32, true>(p, st);
+    case VK_F16: return launch_w<f16_t, 64, 32, true>(p, st);
+  }
+  return VK_ERR_ARG;
+}
+
+}  // namespace vk
+
+extern "C" int vk_conv_wgrad(const vk_conv_desc* d, const void* dz, float* dw, void* stream) {
+  return vk::conv_wgrad_impl(d, dz, dw, (hipStream_t)stream);
+}
+extern "C" int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const void* dz, float* dw_krsc3,
+                             void* stream) {
+  return vk::stem_wgrad_impl(dtype, N, H, W, x4, dz, dw_krsc3, (hipStream_t)stream);
+}

@@ -1,0 +1,765 @@
+// HBM-bound kernels of the U-Net path (everything that is not a convolution GEMM).  All activation
+// tensors are NHWC and are moved as 16-byte vectors; per-channel reductions use wave shuffles + LDS
+// and finish with two fp64 atomics per channel per workgroup.
+// Reference operators replaced (all dispatched by reference train.py:436 model(x) / :438 loss /
+// :443,:448 backward / :449 optimizer.step): batch_norm, relu, max_pool2d, add, interpolate(nearest),
+// cat, BCEWithLogitsLoss, smp DiceLoss, AdamW.
+#include <math.h>
+
+#include "vk_common.h"
+
+namespace vk {
+
+static inline int grid_for(size_t work_items, int block = 256, int max_blocks = 256 * 16) {
+  size_t b = (work_items + block - 1) / block;
+  if (b > (size_t)max_blocks) b = max_blocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: NCHW fp32 -> NHWC4 T
+template <typename T>
+__global__ void k_input_transform(int N, int H, int W, const float* __restrict__ x, T* __restrict__ x4) {
+  const size_t HW = (size_t)H * W, total = (size_t)N * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, hw = i - n * HW;
+    const float* xp = x + n * 3 * HW + hw;
+    T* o = x4 + i * 4;
+    st1(o + 0, xp[0]);
+    st1(o + 1, xp[HW]);
+    st1(o + 2, xp[2 * HW]);
+    st1(o + 3, 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: BatchNorm statistics -> affine
+__global__ void k_bn_finalize(int C, int train, const double* __restrict__ stats, double count,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                              float* running_var, float eps, float momentum, float* scale, float* shift,
+                              float* save_mean, float* save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean, var;
+  if (train) {
+    mean = stats[c] / count;
+    var = stats[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (running_mean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (save_mean) save_mean[c] = (float)mean;
+  if (save_invstd) save_invstd[c] = invstd;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: BN-apply + ReLU + maxpool 3x3 s2 p1 (+ argmax for backward)
+template <typename T>
+__global__ void k_bn_relu_maxpool(int N, int H, int W, int C, const T* __restrict__ z, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, T* __restrict__ pooled, uint8_t* __restrict__ argmax) {
+  constexpr int VE = ElemTraits<T>::kVec;
+  const int Hp = H / 2, Wp = W / 2, CV = C / VE;
+  const size_t total = (size_t)N * Hp * Wp * CV;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    const int pw = (int)(t % Wp);
+    t /= Wp;
+    const int ph = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    float sc[VE], sh[VE], best[VE];
+    int bi[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+      sc[j] = scale[cv * VE + j];
+      sh[j] = shift[cv * VE + j];
+      best[j] = -INFINITY;
+      bi[j] = 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int h = 2 * ph - 1 + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int w = 2 * pw - 1 + s;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(z + (((size_t)n * H + h) * W + w) * C + cv * VE);
+        float f[VE];
+        Vec16<T>::unpack(v, f);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+          const float a = fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f);
+          if (a > best[j]) { best[j] = a; bi[j] = r * 3 + s; }
+        }
+      }
+    }
+    *reinterpret_cast<u32x4_t*>(pooled + i * VE) = Vec16<T>::pack(best);
+    uint8_t* ap = argmax + i * VE;
+    if (VE == 8) {
+      uint32_t lo = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+      uint32_t hi = bi[4 % VE] | (bi[5 % VE] << 8) | (bi[6 % VE] << 16) | (bi[7 % VE] << 24);
+      *reinterpret_cast<u32x2_t*>(ap) = u32x2_t{lo, hi};
+    } else {
+      *reinterpret_cast<uint32_t*>(ap) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+  }
+}
+
+// maxpool backward, gather form: dy[n][h][w][c] += sum over the <=4 windows containing (h,w) whose argmax is (h,w)
+template <typename T>
+__global__ void k_maxpool_bwd(int N, int H, int W, int C, const T* __restrict__ dpool, const uint8_t* __restrict__ argmax,
+                              T* __restrict__ dy) {
+  constexpr int VE = ElemTraits<T>::kVec;
+  const int Hp = H / 2, Wp = W / 2, CV = C / VE;
+  const size_t total = (size_t)N * H * W * CV;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) acc[j] = 0.f;
+    const int ph0 = (h & 1) ? (h - 1) / 2 : h / 2, nph = (h & 1) ? 2 : 1;
+    const int pw0 = (w & 1) ? (w - 1) / 2 : w / 2, npw = (w & 1) ? 2 : 1;
+    bool any = false;
+    for (int a = 0; a < nph; ++a) {
+      const int ph = ph0 + a;
+      if (ph >= Hp) continue;
+      const int r = h - (2 * ph - 1);
+      for (int b = 0; b < npw; ++b) {
+        const int pw = pw0 + b;
+        if (pw >= Wp) continue;
+        const int s = w - (2 * pw - 1);
+        const int code = r * 3 + s;
+        const size_t pi = (((size_t)n * Hp + ph) * Wp + pw) * C + cv * VE;
+        const uint8_t* ap = argmax + pi;
+        uint8_t am[VE];
+        if (VE == 8) {
+          const u32x2_t q = *reinterpret_cast<const u32x2_t*>(ap);
+#pragma unroll
+          for (int j = 0; j < VE; ++j) am[j] = (uint8_t)((q[j >> 2] >> (8 * (j & 3))) & 0xff);
+        } else {
+          const uint32_t q = *reinterpret_cast<const uint32_t*>(ap);
+#pragma unroll
+          for (int j = 0; j < VE; ++j) am[j] = (uint8_t)((q >> (8 * j)) & 0xff);
+        }
+        float g[VE];
+        Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(dpool + pi), g);
+#pragma unroll
+        for (int j = 0; j < VE; ++j)
+          if (am[j] == code) { acc[j] += g[j]; any = true; }
+      }
+    }
+    if (any) {
+      u32x4_t* dp = reinterpret_cast<u32x4_t*>(dy + i * VE);
+      float o[VE];
+      Vec16<T>::unpack(*dp, o);
+#pragma unroll
+      for (int j = 0; j < VE; ++j) o[j] += acc[j];
+      *dp = Vec16<T>::pack(o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: BasicBlock tail  out = relu(bn2(z) + shortcut)
+template <typename T>
+__global__ void k_bn_add_relu(size_t pixels, int C, const T* __restrict__ z, const float* __restrict__ scale,
+                              const float* __restrict__ shift, const T* __restrict__ res, const float* __restrict__ rscale,
+                              const float* __restrict__ rshift, T* __restrict__ out) {
+  constexpr int VE = ElemTraits<T>::kVec;
+  const int CV = C / VE;
+  const size_t total = pixels * CV;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % CV) * VE;
+    float f[VE], r[VE];
+    Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(z + i * VE), f);
+    Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(res + i * VE), r);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+      float v = fmaf(f[j], scale[c0 + j], shift[c0 + j]);
+      const float rr = rscale ? fmaf(r[j], rscale[c0 + j], rshift[c0 + j]) : r[j];
+      f[j] = fmaxf(v + rr, 0.f);
+    }
+    *reinterpret_cast<u32x4_t*>(out + i * VE) = Vec16<T>::pack(f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K13: BatchNorm (+ReLU) backward
+template <typename T, int MASK>
+__device__ __forceinline__ void masked_grad(const T* dy, const T* z, const T* mask_src, size_t off, const float* sc,
+                                            const float* sh, float* g, float* zf) {
+  constexpr int VE = ElemTraits<T>::kVec;
+  Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(dy + off), g);
+  Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(z + off), zf);
+  if (MASK == 1) {
+#pragma unroll
+    for (int j = 0; j < VE; ++j)
+      if (!(fmaf(zf[j], sc[j], sh[j]) > 0.f)) g[j] = 0.f;
+  } else if (MASK == 2) {
+    float m[VE];
+    Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(mask_src + off), m);
+#pragma unroll
+    for (int j = 0; j < VE; ++j)
+      if (!(m[j] > 0.f)) g[j] = 0.f;
+  }
+}
+
+template <typename T, int MASK>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(size_t pixels, int C, const T* __restrict__ dy, const T* __restrict__ z,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const T* __restrict__ mask_src, double* sums) {
+  constexpr int VE = ElemTraits<T>::kVec;
+  const int CV = C / VE;               // <= 128
+  const int rows = 256 / CV;           // pixel rows handled per pass by this block (>= 2)
+  const int tid = threadIdx.x;
+  const int cv = tid % CV, row = tid / CV;
+  const bool active = row < rows;
+  float sc[VE], sh[VE], s1[VE], s2[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) {
+    sc[j] = (MASK == 1) ? scale[cv * VE + j] : 1.f;
+    sh[j] = (MASK == 1) ? shift[cv * VE + j] : 0.f;
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+  }
+  if (active) {
+    for (size_t p = (size_t)blockIdx.x * rows + row; p < pixels; p += (size_t)gridDim.x * rows) {
+      float g[VE], zf[VE];
+      masked_grad<T, MASK>(dy, z, mask_src, p * C + cv * VE, sc, sh, g, zf);
+#pragma unroll
+      for (int j = 0; j < VE; ++j) { s1[j] += g[j]; s2[j] += g[j] * zf[j]; }
+    }
+  }
+  __shared__ float red[256 * 2 * 8];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) {
+    red[(tid * VE + j) * 2] = active ? s1[j] : 0.f;
+    red[(tid * VE + j) * 2 + 1] = active ? s2[j] : 0.f;
+  }
+  __syncthreads();
+  // thread c (< C) sums its channel over the `rows` row-threads
+  for (int c = tid; c < C; c += 256) {
+    const int ccv = c / VE, cj = c % VE;
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < rows; ++r) {
+      const int t = r * CV + ccv;
+      a += red[(t * VE + cj) * 2];
+      b += red[(t * VE + cj) * 2 + 1];
+    }
+    atomicAdd(sums + c, a);
+    atomicAdd(sums + C + c, b);
+  }
+}
+
+__global__ void k_bn_bwd_coeffs(int C, const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* dgamma,
+                                float* dbeta, float* coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = save_mean[c], r = save_invstd[c], ga = gamma[c];
+  const double sg = sums[c], sgz = sums[C + c];
+  const double dg = r * (sgz - mu * sg);     // sum g * xhat
+  const double db = sg;
+  dgamma[c] += (float)dg;
+  dbeta[c] += (float)db;
+  const double a = ga * r;
+  const double b = -ga * r * r * dg / count;
+  const double cc = -a * db / count - b * mu;
+  coef[c] = (float)a;
+  coef[C + c] = (float)b;
+  coef[2 * C + c] = (float)cc;
+}
+
+template <typename T, int MASK>
+__global__ void k_bn_bwd_apply(size_t pixels, int C, const T* __restrict__ dy, const T* __restrict__ z,
+                               const float* __restrict__ scale, const float* __restrict__ shift, const T* __restrict__ mask_src,
+                               const float* __restrict__ coef, T* __restrict__ dz, T* g_out, int g_acc) {
+  constexpr int VE = ElemTraits<T>::kVec;
+  const int CV = C / VE;
+  const size_t total = pixels * CV;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % CV) * VE;
+    float sc[VE], sh[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+      sc[j] = (MASK == 1) ? scale[c0 + j] : 1.f;
+      sh[j] = (MASK == 1) ? shift[c0 + j] : 0.f;
+    }
+    float g[VE], zf[VE], o[VE];
+    masked_grad<T, MASK>(dy, z, mask_src, i * VE, sc, sh, g, zf);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) o[j] = fmaf(coef[c0 + j], g[j], fmaf(coef[C + c0 + j], zf[j], coef[2 * C + c0 + j]));
+    *reinterpret_cast<u32x4_t*>(dz + i * VE) = Vec16<T>::pack(o);
+    if (g_out) {
+      u32x4_t* gp = reinterpret_cast<u32x4_t*>(g_out + i * VE);
+      if (g_acc) {
+        float old[VE];
+        Vec16<T>::unpack(*gp, old);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) g[j] += old[j];
+      }
+      *gp = Vec16<T>::pack(g);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K14: nearest-x2 upsample backward (2x2 sum)
+template <typename T>
+__global__ void k_upsample2x_bwd(int N, int H, int W, int C, const T* __restrict__ d_up, T* __restrict__ d_low, int acc) {
+  constexpr int VE = ElemTraits<T>::kVec;
+  const int Hl = H / 2, Wl = W / 2, CV = C / VE;
+  const size_t total = (size_t)N * Hl * Wl * CV;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    const int wl = (int)(t % Wl);
+    t /= Wl;
+    const int hl = (int)(t % Hl);
+    const int n = (int)(t / Hl);
+    float s[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) s[j] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float f[VE];
+        Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(d_up + (((size_t)n * H + 2 * hl + a) * W + 2 * wl + b) * C + cv * VE), f);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) s[j] += f[j];
+      }
+    u32x4_t* op = reinterpret_cast<u32x4_t*>(d_low + i * VE);
+    if (acc) {
+      float o[VE];
+      Vec16<T>::unpack(*op, o);
+#pragma unroll
+      for (int j = 0; j < VE; ++j) s[j] += o[j];
+    }
+    *op = Vec16<T>::pack(s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9: segmentation head 3x3, 16 -> 1, bias, fp32 logits; input = relu(bn(z)) applied on load
+template <typename T>
+__device__ __forceinline__ void load_act16(const T* p, const float* sc, const float* sh, bool affine, bool relu, float* a) {
+  constexpr int VE = ElemTraits<T>::kVec;
+#pragma unroll
+  for (int v = 0; v < 16 / VE; ++v) Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(p + v * VE), a + v * VE);
+  if (affine) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      a[j] = fmaf(a[j], sc[j], sh[j]);
+      if (relu) a[j] = fmaxf(a[j], 0.f);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_head_fwd(int N, int H, int W, const T* __restrict__ z, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, int relu, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ logits) {
+  __shared__ float ws[144], scs[16], shs[16];
+  const bool affine = scale != nullptr;
+  if (threadIdx.x < 144) ws[threadIdx.x] = w[threadIdx.x];
+  if (threadIdx.x < 16) {
+    scs[threadIdx.x] = affine ? scale[threadIdx.x] : 1.f;
+    shs[threadIdx.x] = affine ? shift[threadIdx.x] : 0.f;
+  }
+  __syncthreads();
+  float sc[16], sh[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { sc[j] = scs[j]; sh[j] = shs[j]; }
+  const float b0 = bias[0];
+  const size_t total = (size_t)N * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int wq = (int)(i % W);
+    const size_t t = i / W;
+    const int hq = (int)(t % H);
+    const size_t n = t / H;
+    float acc = b0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hh = hq + r - 1;
+      if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ww = wq + s - 1;
+        if ((unsigned)ww >= (unsigned)W) continue;
+        float a[16];
+        load_act16<T>(z + ((n * H + hh) * W + ww) * 16, sc, sh, affine, relu != 0, a);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = fmaf(a[j], ws[(r * 3 + s) * 16 + j], acc);
+      }
+    }
+    logits[i] = acc;
+  }
+}
+
+// head backward: dy[m][c] = sum_tap dl[m + (1-r, 1-s)] * w[tap][c];   dw[tap][c] += dl[m + (1-r,1-s)] * a[m][c];  db += dl[m]
+template <typename T>
+__global__ __launch_bounds__(256) void k_head_bwd(int N, int H, int W, const T* __restrict__ z, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, int relu, const float* __restrict__ w,
+                                                  const float* __restrict__ dl, T* __restrict__ dy, float* dw, float* dbias) {
+  __shared__ float ws[144], scs[16], shs[16];
+  __shared__ float red[4][145];
+  const bool affine = scale != nullptr;
+  if (threadIdx.x < 144) ws[threadIdx.x] = w[threadIdx.x];
+  if (threadIdx.x < 16) {
+    scs[threadIdx.x] = affine ? scale[threadIdx.x] : 1.f;
+    shs[threadIdx.x] = affine ? shift[threadIdx.x] : 0.f;
+  }
+  __syncthreads();
+  float sc[16], sh[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { sc[j] = scs[j]; sh[j] = shs[j]; }
+  float gw[144];
+#pragma unroll
+  for (int j = 0; j < 144; ++j) gw[j] = 0.f;
+  float gb = 0.f;
+  const size_t total = (size_t)N * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int wq = (int)(i % W);
+    const size_t t = i / W;
+    const int hq = (int)(t % H);
+    const size_t n = t / H;
+    float a[16], o[16];
+    load_act16<T>(z + i * 16, sc, sh, affine, relu != 0, a);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = 0.f;
+    gb += dl[i];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hh = hq + 1 - r;
+      if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ww = wq + 1 - s;
+        if ((unsigned)ww >= (unsigned)W) continue;
+        const float d = dl[(n * H + hh) * W + ww];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          o[j] = fmaf(d, ws[(r * 3 + s) * 16 + j], o[j]);
+          gw[(r * 3 + s) * 16 + j] = fmaf(d, a[j], gw[(r * 3 + s) * 16 + j]);
+        }
+      }
+    }
+    constexpr int VE = ElemTraits<T>::kVec;
+#pragma unroll
+    for (int v = 0; v < 16 / VE; ++v) *reinterpret_cast<u32x4_t*>(dy + i * 16 + v * VE) = Vec16<T>::pack(o + v * VE);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 144; ++j) {
+    const float v = wave_sum(gw[j]);
+    if (lane == 0) red[wave][j] = v;
+  }
+  {
+    const float v = wave_sum(gb);
+    if (lane == 0) red[wave][144] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 145) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 144) atomicAdd(dw + threadIdx.x, v);
+    else atomicAdd(dbias, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10: BCE-with-logits (mean) + binary Dice (batch-global, smooth 0, eps 1e-7)
+__global__ __launch_bounds__(256) void k_loss_reduce(size_t count, const float* __restrict__ x, const float* __restrict__ y,
+                                                     double* sums) {
+  float bce = 0.f, py = 0.f, ps = 0.f, ys = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const float xv = x[i], yv = y[i];
+    bce += fmaxf(xv, 0.f) - xv * yv + log1pf(expf(-fabsf(xv)));
+    const float p = 1.f / (1.f + expf(-xv));
+    py += p * yv;
+    ps += p;
+    ys += yv;
+  }
+  __shared__ double red[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double a = wave_sum_d((double)bce), b = wave_sum_d((double)py), c = wave_sum_d((double)ps), d = wave_sum_d((double)ys);
+  if (lane == 0) { red[wave][0] = a; red[wave][1] = b; red[wave][2] = c; red[wave][3] = d; }
+  __syncthreads();
+  if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// sums[0..3] = {bce, p*y, p, y}; writes loss_out[0..2] and the two Dice gradient coefficients to sums[4..5]
+__global__ void k_loss_finalize(double count, double* sums, float* loss_out, float w_bce, float w_dice) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double bce = sums[0] / count;
+  const double I = sums[1], card = sums[2] + sums[3], ysum = sums[3];
+  const double eps = 1e-7;
+  const double denom = card > eps ? card : eps;
+  const double mask = ysum > 0.0 ? 1.0 : 0.0;
+  const double dice = (1.0 - 2.0 * I / denom) * mask;
+  loss_out[0] = (float)(w_bce * bce + w_dice * dice);
+  loss_out[1] = (float)bce;
+  loss_out[2] = (float)dice;
+  // d dice / d p_i = -2 (y_i * card - I) / card^2  (clamp inactive whenever mask == 1)
+  sums[4] = card > eps ? -2.0 * w_dice * mask / card : 0.0;            // multiplies y_i
+  sums[5] = card > eps ? 2.0 * w_dice * mask * I / (card * card) : 0.0;  // constant term
+  sums[6] = w_bce / count;
+}
+
+__global__ void k_loss_bwd(size_t count, const float* __restrict__ x, const float* __restrict__ y, const double* __restrict__ sums,
+                           float grad_scale, float* __restrict__ dl) {
+  const float ky = (float)sums[4], k0 = (float)sums[5];
+  const float invc = (float)sums[6];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const float xv = x[i], yv = y[i];
+    const float p = 1.f / (1.f + expf(-xv));
+    const float g = (p - yv) * invc + (ky * yv + k0) * p * (1.f - p);
+    dl[i] = g * grad_scale;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K15: AdamW over the flat fp32 buffers (same arithmetic order as torch/optim/adam.py single-tensor path)
+template <typename LT>
+__global__ void k_adamw(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                        float lr, float beta1, float beta2, float eps, float wd, float step_size, float bc2_sqrt,
+                        float inv_scale, const int* found_inf, LT* lowp) {
+  if (found_inf && *found_inf) return;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * inv_scale;
+    float pi = p[i] * (1.f - lr * wd);
+    float mi = m[i];
+    mi = mi + (gi - mi) * (1.f - beta1);
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - step_size * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (lowp) st1(lowp + i, pi);
+  }
+}
+
+__global__ void k_check_inf(size_t n, const float* __restrict__ g, int* found) {
+  bool bad = false;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    bad |= !isfinite(g[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(found, 1);
+}
+
+}  // namespace vk
+
+// =================================================================================================
+// C ABI wrappers
+// =================================================================================================
+using namespace vk;
+
+#define DISPATCH_T(dt, CALL)                         \
+  switch (dt) {                                      \
+    case VK_F32: { using T = float; CALL; } break;   \
+    case VK_BF16: { using T = bf16_t; CALL; } break; \
+    case VK_F16: { using T = f16_t; CALL; } break;   \
+    default: vkh::set_error("bad dtype %d", (int)dt); return VK_ERR_ARG; \
+  }
+
+extern "C" int vk_input_transform(vk_dtype dtype, int N, int H, int W, const float* x, void* x4, void* stream) {
+  VK_CHECK_ARG(x && x4 && N > 0 && H > 0 && W > 0, "vk_input_transform: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_input_transform<T>, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, st, N, H, W, x, (T*)x4));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_bn_finalize(int C, int train, const double* stats, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float eps, float momentum, float* scale, float* shift,
+                              float* save_mean, float* save_invstd, void* stream) {
+  VK_CHECK_ARG(C > 0 && gamma && beta && scale && shift, "vk_bn_finalize: null argument");
+  VK_CHECK_ARG(train ? (stats != nullptr && count > 0) : (running_mean && running_var), "vk_bn_finalize: missing statistics");
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, train, stats, count, gamma, beta,
+                     running_mean, running_var, eps, momentum, scale, shift, save_mean, save_invstd);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_bn_relu_maxpool(vk_dtype dtype, int N, int H, int W, int C, const void* z, const float* scale,
+                                  const float* shift, void* pooled, uint8_t* argmax, void* stream) {
+  VK_CHECK_ARG(z && scale && shift && pooled && argmax, "vk_bn_relu_maxpool: null argument");
+  VK_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "vk_bn_relu_maxpool: H, W even and C %% 8 == 0 required");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_relu_maxpool<T>, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * (C / ElemTraits<T>::kVec))),
+                                       dim3(256), 0, st, N, H, W, C, (const T*)z, scale, shift, (T*)pooled, argmax));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_maxpool_bwd(vk_dtype dtype, int N, int H, int W, int C, const void* dpool, const uint8_t* argmax, void* dy,
+                              void* stream) {
+  VK_CHECK_ARG(dpool && argmax && dy && C % 8 == 0, "vk_maxpool_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3(grid_for((size_t)N * H * W * (C / ElemTraits<T>::kVec))), dim3(256), 0, st,
+                                       N, H, W, C, (const T*)dpool, argmax, (T*)dy));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_bn_add_relu(vk_dtype dtype, size_t pixels, int C, const void* z, const float* scale, const float* shift,
+                              const void* res, const float* rscale, const float* rshift, void* out, void* stream) {
+  VK_CHECK_ARG(z && scale && shift && res && out && C % 8 == 0, "vk_bn_add_relu: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_add_relu<T>, dim3(grid_for(pixels * (C / ElemTraits<T>::kVec))), dim3(256), 0, st, pixels, C,
+                                       (const T*)z, scale, shift, (const T*)res, rscale, rshift, (T*)out));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+template <typename T>
+static int launch_bn_bwd_reduce(size_t pixels, int C, const void* dy, const void* z, int mask_mode, const float* scale,
+                                const float* shift, const void* mask_src, double* sums, hipStream_t st) {
+  const int CV = C / ElemTraits<T>::kVec;
+  const int rows = 256 / CV;
+  size_t nb = (pixels + rows - 1) / rows;
+  if (nb > 2048) nb = 2048;
+  dim3 grid((unsigned)nb), block(256);
+  if (mask_mode == 0) hipLaunchKernelGGL((k_bn_bwd_reduce<T, 0>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, sums);
+  else if (mask_mode == 1) hipLaunchKernelGGL((k_bn_bwd_reduce<T, 1>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, sums);
+  else hipLaunchKernelGGL((k_bn_bwd_reduce<T, 2>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, sums);
+  return VK_OK;
+}
+
+extern "C" int vk_bn_bwd_reduce(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
+                                const float* scale, const float* shift, const void* mask_src, double* sums, void* stream) {
+  VK_CHECK_ARG(dy && z && sums, "vk_bn_bwd_reduce: null argument");
+  VK_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "vk_bn_bwd_reduce: mask_mode %d", mask_mode);
+  VK_CHECK_ARG(mask_mode != 1 || (scale && shift), "vk_bn_bwd_reduce: mask_mode 1 needs scale/shift");
+  VK_CHECK_ARG(mask_mode != 2 || mask_src, "vk_bn_bwd_reduce: mask_mode 2 needs mask_src");
+  VK_CHECK_ARG(C % 8 == 0 && C <= 512, "vk_bn_bwd_reduce: C=%d unsupported", C);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, launch_bn_bwd_reduce<T>(pixels, C, dy, z, mask_mode, scale, shift, mask_src, sums, st));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_bn_bwd_coeffs(int C, const double* sums, double count, const float* gamma, const float* save_mean,
+                                const float* save_invstd, float* dgamma, float* dbeta, float* coef_abc, void* stream) {
+  VK_CHECK_ARG(sums && gamma && save_mean && save_invstd && dgamma && dbeta && coef_abc, "vk_bn_bwd_coeffs: null argument");
+  hipLaunchKernelGGL(k_bn_bwd_coeffs, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, sums, count, gamma, save_mean,
+                     save_invstd, dgamma, dbeta, coef_abc);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+template <typename T>
+static int launch_bn_bwd_apply(size_t pixels, int C, const void* dy, const void* z, int mask_mode, const float* scale,
+                               const float* shift, const void* mask_src, const float* coef, void* dz, void* g_out, int g_acc,
+                               hipStream_t st) {
+  dim3 grid(grid_for(pixels * (C / ElemTraits<T>::kVec))), block(256);
+  if (mask_mode == 0) hipLaunchKernelGGL((k_bn_bwd_apply<T, 0>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, coef, (T*)dz, (T*)g_out, g_acc);
+  else if (mask_mode == 1) hipLaunchKernelGGL((k_bn_bwd_apply<T, 1>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, coef, (T*)dz, (T*)g_out, g_acc);
+  else hipLaunchKernelGGL((k_bn_bwd_apply<T, 2>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, coef, (T*)dz, (T*)g_out, g_acc);
+  return VK_OK;
+}
+
+extern "C" int vk_bn_bwd_apply(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
+                               const float* scale, const float* shift, const void* mask_src, const float* coef_abc, void* dz,
+                               void* g_out, int g_accumulate, void* stream) {
+  VK_CHECK_ARG(dy && z && coef_abc && dz, "vk_bn_bwd_apply: null argument");
+  VK_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "vk_bn_bwd_apply: mask_mode %d", mask_mode);
+  VK_CHECK_ARG(mask_mode != 1 || (scale && shift), "vk_bn_bwd_apply: mask_mode 1 needs scale/shift");
+  VK_CHECK_ARG(mask_mode != 2 || mask_src, "vk_bn_bwd_apply: mask_mode 2 needs mask_src");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, launch_bn_bwd_apply<T>(pixels, C, dy, z, mask_mode, scale, shift, mask_src, coef_abc, dz, g_out, g_accumulate, st));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_upsample2x_bwd(vk_dtype dtype, int N, int H, int W, int C, const void* d_up, void* d_low, int accumulate,
+                                 void* stream) {
+  VK_CHECK_ARG(d_up && d_low && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "vk_upsample2x_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_upsample2x_bwd<T>, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * (C / ElemTraits<T>::kVec))),
+                                       dim3(256), 0, st, N, H, W, C, (const T*)d_up, (T*)d_low, accumulate));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_head_fwd(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* bias,
+                           float* logits, void* stream) {
+  VK_CHECK_ARG(src && src->ptr && w9x16 && bias && logits, "vk_head_fwd: null argument");
+  VK_CHECK_ARG(src->C == 16 && !src->up, "vk_head_fwd: head input must have 16 channels, no upsample");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_fwd<T>, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, st, N, H, W, (const T*)src->ptr,
+                                       src->scale, src->shift, src->relu, w9x16, bias, logits));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_head_bwd(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* dlogits,
+                           void* dy, float* dw9x16, float* dbias, void* stream) {
+  VK_CHECK_ARG(src && src->ptr && w9x16 && dlogits && dy && dw9x16 && dbias, "vk_head_bwd: null argument");
+  VK_CHECK_ARG(src->C == 16 && !src->up, "vk_head_bwd: head input must have 16 channels, no upsample");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_bwd<T>, dim3(grid_for((size_t)N * H * W, 256, 1024)), dim3(256), 0, st, N, H, W,
+                                       (const T*)src->ptr, src->scale, src->shift, src->relu, w9x16, dlogits, (T*)dy, dw9x16, dbias));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_bce_dice_loss(size_t count, const float* logits, const float* target, double* sums, float* loss_out,
+                                float* dlogits, float grad_scale, float w_bce, float w_dice, void* stream) {
+  VK_CHECK_ARG(count > 0 && logits && target && sums && loss_out, "vk_bce_dice_loss: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  VK_CHECK_HIP(hipMemsetAsync(sums, 0, 8 * sizeof(double), st));
+  hipLaunchKernelGGL(k_loss_reduce, dim3(grid_for(count, 256, 1024)), dim3(256), 0, st, count, logits, target, sums);
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, (double)count, sums, loss_out, w_bce, w_dice);
+  if (dlogits) hipLaunchKernelGGL(k_loss_bwd, dim3(grid_for(count)), dim3(256), 0, st, count, logits, target, sums, grad_scale, dlogits);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_adamw_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float inv_scale, const int* found_inf,
+                             void* lowp_copy, vk_dtype lowp_dtype, void* stream) {
+  VK_CHECK_ARG(n > 0 && param && grad && exp_avg && exp_avg_sq && step >= 1, "vk_adamw_step: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(grid_for(n)), block(256);
+  if (!lowp_copy || lowp_dtype == VK_F32) {
+    hipLaunchKernelGGL(k_adamw<float>, grid, block, 0, st, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                       step_size, bc2_sqrt, inv_scale, found_inf, (float*)nullptr);
+  } else if (lowp_dtype == VK_BF16) {
+    hipLaunchKernelGGL(k_adamw<bf16_t>, grid, block, 0, st, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                       step_size, bc2_sqrt, inv_scale, found_inf, (bf16_t*)lowp_copy);
+  } else {
+    hipLaunchKernelGGL(k_adamw<f16_t>, grid, block, 0, st, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                       step_size, bc2_sqrt, inv_scale, found_inf, (f16_t*)lowp_copy);
+  }
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_amp_check_inf(size_t n, const float* grad, int* found_inf, void* stream) {
+  VK_CHECK_ARG(n > 0 && grad && found_inf, "vk_amp_check_inf: null argument");
+  hipLaunchKernelGGL(k_check_inf, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, grad, found_inf);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}

@@ -1,0 +1,843 @@
+// The U-Net plan: smp.Unet("resnet34", in_channels=3, classes=1) as a static schedule of the HIP
+// kernels in this directory.  Mirrors the reference composition: train.py:372-378 (constructor
+// arguments), train.py:436 (forward), :438 (BCE + Dice), :443/:448 (backward); topology restated
+// from smp.  Host-only code except for the small weight-packing kernels.
+//
+// Memory model: the caller owns four flat buffers (fp32 params, fp32 grads, fp32 BN running stats,
+// int64 num_batches_tracked) plus one workspace; this file only computes offsets into them.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "vk_common.h"
+
+namespace vkh {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace vkh
+
+extern "C" int vk_version(void) { return VK_ABI_VERSION; }
+extern "C" const char* vk_last_error_string(void) { return vkh::g_err; }
+
+namespace vk {
+
+__global__ void k_probe() {}
+
+// ---------------------------------------------------------------- weight packing kernels
+struct PackEntry {
+  int64_t src, dst;     // element offsets: flat params / dgrad arena
+  int K, RS, C, pad_;
+};
+
+// dgrad pack: arena[dst + (c*RS + t)*K + k] = T(params[src + (k*RS + t)*C + c])   (LDS-tiled transpose)
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_dgrad(const PackEntry* __restrict__ tab, const float* __restrict__ params,
+                                                    T* __restrict__ arena) {
+  const PackEntry e = tab[blockIdx.y];
+  __shared__ float tl[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int kt_n = (e.K + 31) / 32, ct_n = (e.C + 31) / 32;
+  const int ntile = kt_n * ct_n * e.RS;
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int t = tile % e.RS;
+    const int rem = tile / e.RS;
+    const int ct = rem % ct_n, kt = rem / ct_n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kt * 32 + ty + 8 * i, c = ct * 32 + tx;
+      tl[ty + 8 * i][tx] = (k < e.K && c < e.C) ? params[e.src + ((int64_t)k * e.RS + t) * e.C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = ct * 32 + ty + 8 * i, k = kt * 32 + tx;
+      if (k < e.K && c < e.C) st1(arena + e.dst + ((int64_t)c * e.RS + t) * e.K + k, tl[tx][ty + 8 * i]);
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ void k_cast_flat(size_t n, const float* __restrict__ src, T* __restrict__ dst) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st1(dst + i, src[i]);
+}
+
+// stem pack: wp[k][r][s*4 + c] = w[k][r][s][c] (s < 7, c < 3), zero elsewhere;  w is KRSC [64][7][7][3]
+template <typename T>
+__global__ void k_pack_stem(const float* __restrict__ w, T* __restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * 7 * 32) return;
+  const int j = i % 32, r = (i / 32) % 7, k = i / (32 * 7);
+  const int s = j >> 2, c = j & 3;
+  const float v = (s < 7 && c < 3) ? w[((k * 7 + r) * 7 + s) * 3 + c] : 0.f;
+  st1(wp + i, v);
+}
+
+struct BnEvalEntry {
+  int64_t g_off, b_off, rm_off, rv_off, out_off;   // out_off: scale at out_off, shift at out_off + C
+  int C, pad_;
+};
+__global__ void k_bn_eval_all(const BnEvalEntry* __restrict__ tab, const float* __restrict__ params, const float* __restrict__ bufs,
+                              float* __restrict__ arena, float eps) {
+  const BnEvalEntry e = tab[blockIdx.x];
+  for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+    const float invstd = (float)(1.0 / sqrt((double)bufs[e.rv_off + c] + (double)eps));
+    const float sc = params[e.g_off + c] * invstd;
+    arena[e.out_off + c] = sc;
+    arena[e.out_off + e.C + c] = params[e.b_off + c] - bufs[e.rm_off + c] * sc;
+  }
+}
+
+__global__ void k_inc_i64(int n, int64_t* p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] += 1;
+}
+
+// ---------------------------------------------------------------- plan structures
+struct ConvL {
+  std::string name;       // state-dict prefix; weight key = name + ".weight"
+  int Cin, K, R, stride, pad;
+  int64_t w_off;          // flat params (KRSC)
+  int64_t wd_off;         // dgrad arena offset (-1: none)
+  int bn;                 // following BN (-1 for the head)
+  int Hin, Hout;          // square spatial sizes
+  // workspace
+  char* z = nullptr;      // raw conv output [N][Hout][Hout][K]
+  char* g = nullptr;      // gradient wrt activated output, overwritten in place by gradient wrt z
+};
+
+struct BnL {
+  std::string name;
+  int C;
+  int64_t g_off, b_off, rm_off, rv_off;
+  int idx;
+  double count;           // N*H*W
+  // workspace
+  double* stats = nullptr;      // [2C] forward sums
+  double* bsums = nullptr;      // [2C] backward sums
+  float* scale = nullptr;       // [C]
+  float* shift = nullptr;
+  float* mean = nullptr;
+  float* invstd = nullptr;
+  float* coef = nullptr;        // [3C]
+  int64_t arena_off = 0;        // offset of scale in the float arena
+};
+
+struct BlockL {
+  int conv1, conv2, convd;      // convd = -1 for identity shortcut
+  int Cin, C, stride, Hin, Hout;
+  bool in_has_grad_first;       // gradient buffer of the block input was already written (skip feature)
+  char* out = nullptr;
+  char* gout = nullptr;
+};
+
+struct DecL {
+  int conv1, conv2;
+  int Cup, Cskip, Cout, H;      // H = output resolution
+};
+
+struct Act {                     // a (possibly virtual) activated tensor
+  const void* ptr;
+  int C;
+  const float* scale;
+  const float* shift;
+  int relu;
+};
+
+}  // namespace vk
+
+using namespace vk;
+
+struct vk_unet {
+  vk_unet_config cfg;
+  int eb;                        // element bytes of the activation dtype
+  std::vector<vk_tensor_info> infos;
+  std::vector<ConvL> convs;
+  std::vector<BnL> bns;
+  std::vector<BlockL> blocks;
+  std::vector<DecL> decs;
+  int stem_conv = -1, head_conv = -1;
+  int layer_last_block[4];
+  int64_t n_params = 0, n_bufs = 0, n_dgrad = 0;
+  int64_t head_w_off = 0, head_b_off = 0;
+  std::vector<std::pair<int64_t, int64_t>> buckets;
+  // workspace layout
+  size_t ws_bytes = 0;
+  size_t off_x4 = 0, off_pool = 0, off_argmax = 0, off_gpool = 0, off_dup = 0, off_dlogits = 0, off_loss_sums = 0;
+  size_t off_stats = 0, off_bsums = 0, stats_bytes = 0, off_farena = 0, farena_floats = 0, off_wf = 0, off_wd = 0, off_wstem = 0;
+  size_t off_tab_pack = 0, off_tab_bn = 0;
+  std::vector<size_t> off_z, off_g, off_out, off_gout;
+  // bound pointers
+  float* params = nullptr;
+  float* grads = nullptr;
+  float* bufs = nullptr;
+  int64_t* nbt = nullptr;
+  char* ws = nullptr;
+  bool bound = false;
+  std::vector<PackEntry> pack_tab;
+  std::vector<BnEvalEntry> bn_tab;
+  std::map<std::string, std::pair<void*, std::vector<int>>> debug;
+
+  int N() const { return cfg.N; }
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void add_info(vk_unet* h, const std::string& name, int kind, std::vector<int> dims, int64_t offset, int64_t numel) {
+  vk_tensor_info ti;
+  memset(&ti, 0, sizeof(ti));
+  snprintf(ti.name, sizeof(ti.name), "%s", name.c_str());
+  ti.kind = kind;
+  ti.ndim = (int)dims.size();
+  for (size_t i = 0; i < dims.size() && i < 4; ++i) ti.dims[i] = dims[i];
+  ti.offset = offset;
+  ti.numel = numel;
+  h->infos.push_back(ti);
+}
+
+int add_conv(vk_unet* h, const std::string& name, int Cin, int K, int R, int stride, int pad, int Hin, bool bias = false) {
+  ConvL c;
+  c.name = name;
+  c.Cin = Cin; c.K = K; c.R = R; c.stride = stride; c.pad = pad;
+  c.Hin = Hin;
+  c.Hout = (Hin + 2 * pad - R) / stride + 1;
+  c.w_off = h->n_params;
+  c.wd_off = -1;
+  c.bn = -1;
+  const int64_t numel = (int64_t)K * Cin * R * R;
+  add_info(h, name + ".weight", 0, {K, Cin, R, R}, c.w_off, numel);
+  h->n_params += (int64_t)align_up((size_t)numel, 4);
+  if (bias) {
+    add_info(h, name + ".bias", 1, {K}, h->n_params, K);
+    h->n_params += 4;
+  }
+  h->convs.push_back(c);
+  return (int)h->convs.size() - 1;
+}
+
+int add_bn(vk_unet* h, const std::string& name, int C, double count) {
+  BnL b;
+  b.name = name;
+  b.C = C;
+  b.count = count;
+  b.idx = (int)h->bns.size();
+  b.g_off = h->n_params;
+  add_info(h, name + ".weight", 1, {C}, b.g_off, C);
+  h->n_params += C;
+  b.b_off = h->n_params;
+  add_info(h, name + ".bias", 1, {C}, b.b_off, C);
+  h->n_params += C;
+  b.rm_off = h->n_bufs;
+  add_info(h, name + ".running_mean", 2, {C}, b.rm_off, C);
+  h->n_bufs += C;
+  b.rv_off = h->n_bufs;
+  add_info(h, name + ".running_var", 2, {C}, b.rv_off, C);
+  h->n_bufs += C;
+  add_info(h, name + ".num_batches_tracked", 3, {}, b.idx, 1);
+  h->bns.push_back(b);
+  return b.idx;
+}
+
+void build_topology(vk_unet* h) {
+  const int S = h->cfg.size, N = h->cfg.N;
+  auto cnt = [&](int Hres) { return (double)N * Hres * Hres; };
+  // --- encoder stem
+  h->stem_conv = add_conv(h, "encoder.conv1", 3, 64, 7, 2, 3, S);
+  h->convs[h->stem_conv].bn = add_bn(h, "encoder.bn1", 64, cnt(S / 2));
+  // --- encoder layers
+  const int nblocks[4] = {3, 4, 6, 3};
+  const int planes[4] = {64, 128, 256, 512};
+  int inpl = 64, res = S / 4;
+  std::vector<int64_t> layer_start(4), layer3_mid(1);
+  std::vector<int64_t> block_start;
+  for (int L = 0; L < 4; ++L) {
+    layer_start[L] = h->n_params;
+    for (int b = 0; b < nblocks[L]; ++b) {
+      block_start.push_back(h->n_params);
+      const int stride = (b == 0 && L > 0) ? 2 : 1;
+      const std::string pre = "encoder.layer" + std::to_string(L + 1) + "." + std::to_string(b);
+      BlockL blk;
+      blk.Cin = inpl; blk.C = planes[L]; blk.stride = stride; blk.Hin = res; blk.Hout = res / stride;
+      blk.conv1 = add_conv(h, pre + ".conv1", inpl, planes[L], 3, stride, 1, res);
+      h->convs[blk.conv1].bn = add_bn(h, pre + ".bn1", planes[L], cnt(blk.Hout));
+      blk.conv2 = add_conv(h, pre + ".conv2", planes[L], planes[L], 3, 1, 1, blk.Hout);
+      h->convs[blk.conv2].bn = add_bn(h, pre + ".bn2", planes[L], cnt(blk.Hout));
+      blk.convd = -1;
+      if (stride != 1 || inpl != planes[L]) {
+        blk.convd = add_conv(h, pre + ".downsample.0", inpl, planes[L], 1, stride, 0, res);
+        h->convs[blk.convd].bn = add_bn(h, pre + ".downsample.1", planes[L], cnt(blk.Hout));
+      }
+      // the input of block 0 of layers 2-4 is a skip feature whose gradient the decoder wrote first
+      blk.in_has_grad_first = (b == 0 && L > 0);
+      h->blocks.push_back(blk);
+      inpl = planes[L];
+      res = blk.Hout;
+    }
+    h->layer_last_block[L] = (int)h->blocks.size() - 1;
+  }
+  // --- decoder
+  const int dec_in[5] = {512, 256, 128, 64, 32};
+  const int dec_skip[5] = {256, 128, 64, 64, 0};
+  const int dec_out[5] = {256, 128, 64, 32, 16};
+  std::vector<int64_t> dec_start(5);
+  int dres = S / 32;
+  for (int i = 0; i < 5; ++i) {
+    dec_start[i] = h->n_params;
+    dres *= 2;
+    const std::string pre = "decoder.blocks." + std::to_string(i);
+    DecL d;
+    d.Cup = dec_in[i]; d.Cskip = dec_skip[i]; d.Cout = dec_out[i]; d.H = dres;
+    d.conv1 = add_conv(h, pre + ".conv1.0", dec_in[i] + dec_skip[i], dec_out[i], 3, 1, 1, dres);
+    h->convs[d.conv1].bn = add_bn(h, pre + ".conv1.1", dec_out[i], cnt(dres));
+    d.conv2 = add_conv(h, pre + ".conv2.0", dec_out[i], dec_out[i], 3, 1, 1, dres);
+    h->convs[d.conv2].bn = add_bn(h, pre + ".conv2.1", dec_out[i], cnt(dres));
+    h->decs.push_back(d);
+  }
+  // --- head
+  const int64_t head_start = h->n_params;
+  (void)head_start;
+  h->head_conv = add_conv(h, "segmentation_head.0", 16, 1, 3, 1, 1, S, /*bias=*/true);
+  h->head_w_off = h->convs[h->head_conv].w_off;
+  h->head_b_off = h->head_w_off + 144;
+  h->n_params = (int64_t)align_up((size_t)h->n_params, 64);
+  // --- dgrad arena offsets
+  for (size_t i = 0; i < h->convs.size(); ++i) {
+    if ((int)i == h->stem_conv || (int)i == h->head_conv) continue;
+    ConvL& c = h->convs[i];
+    c.wd_off = h->n_dgrad;
+    h->n_dgrad += (int64_t)align_up((size_t)c.K * c.Cin * c.R * c.R, 8);
+  }
+  // --- gradient buckets in backward completion order (stage i completes bucket i)
+  const int64_t P = h->n_params;
+  // block_start indices: layer1: 0..2, layer2: 3..6, layer3: 7..12, layer4: 13..15
+  h->buckets.push_back({dec_start[2], P});                       // stage 0: head + dec4 + dec3 + dec2
+  h->buckets.push_back({dec_start[1], dec_start[2]});            // 1: dec1
+  h->buckets.push_back({dec_start[0], dec_start[1]});            // 2: dec0
+  h->buckets.push_back({block_start[15], dec_start[0]});         // 3: layer4.2
+  h->buckets.push_back({block_start[14], block_start[15]});      // 4: layer4.1
+  h->buckets.push_back({block_start[13], block_start[14]});      // 5: layer4.0
+  h->buckets.push_back({block_start[10], block_start[13]});      // 6: layer3.3-5
+  h->buckets.push_back({block_start[7], block_start[10]});       // 7: layer3.0-2
+  h->buckets.push_back({block_start[3], block_start[7]});        // 8: layer2
+  h->buckets.push_back({0, block_start[3]});                     // 9: layer1 + stem
+}
+
+void layout_workspace(vk_unet* h) {
+  const int N = h->cfg.N, S = h->cfg.size, eb = h->eb;
+  const bool tr = h->cfg.training != 0;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  h->off_x4 = take((size_t)N * S * S * 4 * eb);
+  h->off_z.resize(h->convs.size());
+  h->off_g.assign(h->convs.size(), 0);
+  for (size_t i = 0; i < h->convs.size(); ++i) {
+    const ConvL& c = h->convs[i];
+    if ((int)i == h->head_conv) { h->off_z[i] = 0; continue; }
+    const size_t bytes = (size_t)N * c.Hout * c.Hout * c.K * eb;
+    h->off_z[i] = take(bytes);
+    if (tr) h->off_g[i] = take(bytes);
+  }
+  h->off_pool = take((size_t)N * (S / 4) * (S / 4) * 64 * eb);
+  h->off_argmax = take((size_t)N * (S / 4) * (S / 4) * 64);
+  if (tr) h->off_gpool = take((size_t)N * (S / 4) * (S / 4) * 64 * eb);
+  h->off_out.resize(h->blocks.size());
+  h->off_gout.assign(h->blocks.size(), 0);
+  for (size_t b = 0; b < h->blocks.size(); ++b) {
+    const BlockL& k = h->blocks[b];
+    const size_t bytes = (size_t)N * k.Hout * k.Hout * k.C * eb;
+    h->off_out[b] = take(bytes);
+    if (tr) h->off_gout[b] = take(bytes);
+  }
+  if (tr) {
+    size_t mx = 0;
+    for (const DecL& d : h->decs) mx = std::max(mx, (size_t)N * d.H * d.H * d.Cup * eb);
+    h->off_dup = take(mx);
+    h->off_dlogits = take((size_t)N * S * S * 4);
+  }
+  h->off_loss_sums = take(8 * sizeof(double));
+  // per-BN statistics (one zero region) and float arena
+  size_t st = 0, fl = 0;
+  for (BnL& b : h->bns) {
+    st += 2 * (size_t)b.C * sizeof(double);
+    b.arena_off = (int64_t)fl;
+    fl += 7 * (size_t)b.C;
+  }
+  h->stats_bytes = st;
+  h->off_stats = take(st);
+  h->off_bsums = take(st);
+  h->farena_floats = fl;
+  h->off_farena = take(fl * sizeof(float));
+  h->off_wf = (eb == 4) ? 0 : take((size_t)h->n_params * eb);
+  h->off_wd = tr ? take((size_t)h->n_dgrad * eb) : 0;
+  h->off_wstem = take(64 * 7 * 32 * eb);
+  h->off_tab_pack = take(h->convs.size() * sizeof(PackEntry));
+  h->off_tab_bn = take(h->bns.size() * sizeof(BnEvalEntry));
+  h->ws_bytes = off;
+}
+
+void assign_pointers(vk_unet* h) {
+  char* ws = h->ws;
+  h->debug.clear();
+  const int N = h->cfg.N;
+  for (size_t i = 0; i < h->convs.size(); ++i) {
+    ConvL& c = h->convs[i];
+    if ((int)i == h->head_conv) continue;
+    c.z = ws + h->off_z[i];
+    c.g = h->cfg.training ? ws + h->off_g[i] : nullptr;
+    h->debug["z:" + c.name] = {c.z, {N, c.Hout, c.Hout, c.K}};
+    if (c.g) h->debug["g:" + c.name] = {c.g, {N, c.Hout, c.Hout, c.K}};
+  }
+  for (size_t b = 0; b < h->blocks.size(); ++b) {
+    BlockL& k = h->blocks[b];
+    k.out = ws + h->off_out[b];
+    k.gout = h->cfg.training ? ws + h->off_gout[b] : nullptr;
+    const std::string nm = h->convs[k.conv1].name.substr(0, h->convs[k.conv1].name.size() - 6);  // strip ".conv1"
+    h->debug["out:" + nm] = {k.out, {N, k.Hout, k.Hout, k.C}};
+    if (k.gout) h->debug["gout:" + nm] = {k.gout, {N, k.Hout, k.Hout, k.C}};
+  }
+  const int S = h->cfg.size;
+  h->debug["x4"] = {ws + h->off_x4, {N, S, S, 4}};
+  h->debug["pool"] = {ws + h->off_pool, {N, S / 4, S / 4, 64}};
+  if (h->cfg.training) {
+    h->debug["gpool"] = {ws + h->off_gpool, {N, S / 4, S / 4, 64}};
+    h->debug["dlogits"] = {ws + h->off_dlogits, {N, S, S, 1}};
+  }
+  double* sp = (double*)(ws + h->off_stats);
+  double* bp = (double*)(ws + h->off_bsums);
+  float* fa = (float*)(ws + h->off_farena);
+  for (BnL& b : h->bns) {
+    b.stats = sp;
+    b.bsums = bp;
+    sp += 2 * b.C;
+    bp += 2 * b.C;
+    float* f = fa + b.arena_off;
+    b.scale = f;
+    b.shift = f + b.C;
+    b.mean = f + 2 * b.C;
+    b.invstd = f + 3 * b.C;
+    b.coef = f + 4 * b.C;
+    h->debug["scale:" + b.name] = {b.scale, {b.C}};
+    h->debug["shift:" + b.name] = {b.shift, {b.C}};
+  }
+}
+
+const void* fwd_weights(const vk_unet* h, const ConvL& c) {
+  if (h->eb == 4) return h->params + c.w_off;
+  return h->ws + h->off_wf + (size_t)c.w_off * h->eb;
+}
+const void* dgrad_weights(const vk_unet* h, const ConvL& c) { return h->ws + h->off_wd + (size_t)c.wd_off * h->eb; }
+
+vk_src to_src(const Act& a, int up = 0) {
+  vk_src s;
+  s.ptr = a.ptr; s.C = a.C; s.up = up; s.scale = a.scale; s.shift = a.shift; s.relu = a.relu;
+  return s;
+}
+vk_src null_src() {
+  vk_src s;
+  memset(&s, 0, sizeof(s));
+  return s;
+}
+
+vk_conv_desc conv_desc(const vk_unet* h, const ConvL& c, const vk_src& s0, const vk_src& s1) {
+  vk_conv_desc d;
+  d.dtype = h->cfg.dtype;
+  d.N = h->cfg.N; d.H = c.Hin; d.W = c.Hin; d.Ho = c.Hout; d.Wo = c.Hout;
+  d.K = c.K; d.R = c.R; d.S = c.R; d.stride = c.stride; d.pad = c.pad; d.transposed = 0;
+  d.src0 = s0; d.src1 = s1;
+  return d;
+}
+
+Act bn_act(const vk_unet* h, const ConvL& c) {   // relu(bn(z)) as a virtual tensor
+  const BnL& b = h->bns[c.bn];
+  return Act{c.z, c.K, b.scale, b.shift, 1};
+}
+
+#define RET_IF(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != VK_OK) return rc_; \
+  } while (0)
+
+int finalize_bn(vk_unet* h, BnL& b, int training, hipStream_t st) {
+  if (!training) return VK_OK;   // eval affine was produced for all layers at the start of forward
+  return vk_bn_finalize(b.C, 1, b.stats, b.count, h->params + b.g_off, h->params + b.b_off, h->bufs + b.rm_off,
+                        h->bufs + b.rv_off, 1e-5f, 0.1f, b.scale, b.shift, b.mean, b.invstd, st);
+}
+
+int run_conv(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, int training, hipStream_t st) {
+  vk_conv_desc d = conv_desc(h, c, s0, s1);
+  BnL& b = h->bns[c.bn];
+  RET_IF(vk_conv_fwd(&d, fwd_weights(h, c), c.z, nullptr, 0, 0, training ? b.stats : nullptr, st));
+  return finalize_bn(h, b, training, st);
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" int vk_has_gfx950_code(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, (const void*)vk::k_probe) == hipSuccess ? 1 : 0;
+}
+
+extern "C" int vk_unet_create(const vk_unet_config* cfg, vk_unet** out) {
+  VK_CHECK_ARG(cfg && out, "vk_unet_create: null argument");
+  VK_CHECK_ARG(cfg->N >= 1 && cfg->size >= 32 && cfg->size % 32 == 0,
+               "Wrong input shape height=%d, width=%d: must be divisible by 32", cfg->size, cfg->size);
+  VK_CHECK_ARG(cfg->dtype == VK_F32 || cfg->dtype == VK_BF16 || cfg->dtype == VK_F16, "vk_unet_create: bad dtype");
+  vk_unet* h = new vk_unet();
+  h->cfg = *cfg;
+  h->eb = cfg->dtype == VK_F32 ? 4 : 2;
+  build_topology(h);
+  layout_workspace(h);
+  *out = h;
+  return VK_OK;
+}
+
+extern "C" void vk_unet_destroy(vk_unet* h) { delete h; }
+extern "C" int vk_unet_num_tensors(const vk_unet* h) { return h ? (int)h->infos.size() : 0; }
+extern "C" int vk_unet_tensor_info(const vk_unet* h, int index, vk_tensor_info* out) {
+  VK_CHECK_ARG(h && out && index >= 0 && index < (int)h->infos.size(), "vk_unet_tensor_info: bad index %d", index);
+  *out = h->infos[index];
+  return VK_OK;
+}
+extern "C" int64_t vk_unet_param_numel(const vk_unet* h) { return h ? h->n_params : 0; }
+extern "C" int64_t vk_unet_buffer_numel(const vk_unet* h) { return h ? h->n_bufs : 0; }
+extern "C" int64_t vk_unet_workspace_bytes(const vk_unet* h) { return h ? (int64_t)h->ws_bytes : 0; }
+extern "C" int vk_unet_num_buckets(const vk_unet* h) { return h ? (int)h->buckets.size() : 0; }
+extern "C" int vk_unet_bucket_range(const vk_unet* h, int bucket, int64_t* b, int64_t* e) {
+  VK_CHECK_ARG(h && b && e && bucket >= 0 && bucket < (int)h->buckets.size(), "vk_unet_bucket_range: bad bucket %d", bucket);
+  *b = h->buckets[bucket].first;
+  *e = h->buckets[bucket].second;
+  return VK_OK;
+}
+
+extern "C" int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_buffers, int64_t* nbt, void* workspace,
+                            size_t workspace_bytes) {
+  VK_CHECK_ARG(h && params && bn_buffers && nbt && workspace, "vk_unet_bind: null argument");
+  VK_CHECK_ARG(!h->cfg.training || grads, "vk_unet_bind: a training plan needs a gradient buffer");
+  VK_CHECK_ARG(workspace_bytes >= h->ws_bytes, "vk_unet_bind: workspace too small (%zu < %zu)", workspace_bytes, h->ws_bytes);
+  VK_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)params & 15) == 0, "vk_unet_bind: buffers must be 256-byte (workspace) / 16-byte (params) aligned");
+  h->params = params; h->grads = grads; h->bufs = bn_buffers; h->nbt = nbt; h->ws = (char*)workspace;
+  assign_pointers(h);
+  // device tables
+  h->pack_tab.clear();
+  for (size_t i = 0; i < h->convs.size(); ++i) {
+    const ConvL& c = h->convs[i];
+    if (c.wd_off < 0) continue;
+    PackEntry e;
+    e.src = c.w_off; e.dst = c.wd_off; e.K = c.K; e.RS = c.R * c.R; e.C = c.Cin; e.pad_ = 0;
+    h->pack_tab.push_back(e);
+  }
+  h->bn_tab.clear();
+  for (const BnL& b : h->bns) {
+    BnEvalEntry e;
+    e.g_off = b.g_off; e.b_off = b.b_off; e.rm_off = b.rm_off; e.rv_off = b.rv_off; e.out_off = b.arena_off; e.C = b.C; e.pad_ = 0;
+    h->bn_tab.push_back(e);
+  }
+  VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_pack, h->pack_tab.data(), h->pack_tab.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
+  VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_bn, h->bn_tab.data(), h->bn_tab.size() * sizeof(BnEvalEntry), hipMemcpyHostToDevice));
+  h->bound = true;
+  return VK_OK;
+}
+
+template <typename T>
+static int refresh_t(vk_unet* h, hipStream_t st) {
+  if (sizeof(T) != 4)
+    hipLaunchKernelGGL(k_cast_flat<T>, dim3(2048), dim3(256), 0, st, (size_t)h->n_params, h->params, (T*)(h->ws + h->off_wf));
+  if (h->cfg.training && !h->pack_tab.empty())
+    hipLaunchKernelGGL(k_pack_dgrad<T>, dim3(64, (unsigned)h->pack_tab.size()), dim3(256), 0, st,
+                       (const PackEntry*)(h->ws + h->off_tab_pack), h->params, (T*)(h->ws + h->off_wd));
+  hipLaunchKernelGGL(k_pack_stem<T>, dim3((64 * 7 * 32 + 255) / 256), dim3(256), 0, st,
+                     h->params + h->convs[h->stem_conv].w_off, (T*)(h->ws + h->off_wstem));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_unet_refresh_weights(vk_unet* h, void* stream) {
+  VK_CHECK_ARG(h && h->bound, "vk_unet_refresh_weights: plan not bound");
+  hipStream_t st = (hipStream_t)stream;
+  switch (h->cfg.dtype) {
+    case VK_F32: return refresh_t<float>(h, st);
+    case VK_BF16: return refresh_t<bf16_t>(h, st);
+    case VK_F16: return refresh_t<f16_t>(h, st);
+  }
+  return VK_ERR_ARG;
+}
+
+extern "C" int vk_unet_zero_grad(vk_unet* h, void* stream) {
+  VK_CHECK_ARG(h && h->bound && h->grads, "vk_unet_zero_grad: no gradient buffer bound");
+  VK_CHECK_HIP(hipMemsetAsync(h->grads, 0, (size_t)h->n_params * sizeof(float), (hipStream_t)stream));
+  return VK_OK;
+}
+
+extern "C" int vk_unet_debug_tensor(const vk_unet* h, const char* name, void** ptr, int dims[4]) {
+  VK_CHECK_ARG(h && h->bound && name && ptr && dims, "vk_unet_debug_tensor: bad argument");
+  auto it = h->debug.find(name);
+  VK_CHECK_ARG(it != h->debug.end(), "vk_unet_debug_tensor: unknown tensor '%s'", name);
+  *ptr = it->second.first;
+  for (int i = 0; i < 4; ++i) dims[i] = i < (int)it->second.second.size() ? it->second.second[i] : 1;
+  return VK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+extern "C" int vk_unet_forward(vk_unet* h, const float* x, float* logits, int training, void* stream) {
+  VK_CHECK_ARG(h && h->bound && x && logits, "vk_unet_forward: plan not bound or null tensor");
+  VK_CHECK_ARG(!training || h->cfg.training, "vk_unet_forward: training forward needs a training plan");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = h->cfg.N, S = h->cfg.size;
+  const vk_dtype dt = h->cfg.dtype;
+  if (training) {
+    VK_CHECK_HIP(hipMemsetAsync(h->ws + h->off_stats, 0, h->stats_bytes, st));
+  } else {
+    hipLaunchKernelGGL(k_bn_eval_all, dim3((unsigned)h->bns.size()), dim3(128), 0, st, (const BnEvalEntry*)(h->ws + h->off_tab_bn),
+                       h->params, h->bufs, (float*)(h->ws + h->off_farena), 1e-5f);
+    VK_CHECK_HIP(hipGetLastError());
+  }
+  // stem
+  void* x4 = h->ws + h->off_x4;
+  RET_IF(vk_input_transform(dt, N, S, S, x, x4, st));
+  ConvL& stem = h->convs[h->stem_conv];
+  BnL& sbn = h->bns[stem.bn];
+  RET_IF(vk_stem_fwd(dt, N, S, S, x4, h->ws + h->off_wstem, stem.z, training ? sbn.stats : nullptr, st));
+  RET_IF(finalize_bn(h, sbn, training, st));
+  void* pool = h->ws + h->off_pool;
+  RET_IF(vk_bn_relu_maxpool(dt, N, S / 2, S / 2, 64, stem.z, sbn.scale, sbn.shift, pool, (uint8_t*)(h->ws + h->off_argmax), st));
+  // encoder blocks
+  Act cur{pool, 64, nullptr, nullptr, 0};
+  for (BlockL& k : h->blocks) {
+    ConvL& c1 = h->convs[k.conv1];
+    ConvL& c2 = h->convs[k.conv2];
+    RET_IF(run_conv(h, c1, to_src(cur), null_src(), training, st));
+    RET_IF(run_conv(h, c2, to_src(bn_act(h, c1)), null_src(), training, st));
+    const BnL& b2 = h->bns[c2.bn];
+    const size_t pixels = (size_t)N * k.Hout * k.Hout;
+    if (k.convd >= 0) {
+      ConvL& cd = h->convs[k.convd];
+      RET_IF(run_conv(h, cd, to_src(cur), null_src(), training, st));
+      const BnL& bd = h->bns[cd.bn];
+      RET_IF(vk_bn_add_relu(dt, pixels, k.C, c2.z, b2.scale, b2.shift, cd.z, bd.scale, bd.shift, k.out, st));
+    } else {
+      RET_IF(vk_bn_add_relu(dt, pixels, k.C, c2.z, b2.scale, b2.shift, cur.ptr, nullptr, nullptr, k.out, st));
+    }
+    cur = Act{k.out, k.C, nullptr, nullptr, 0};
+  }
+  // decoder
+  Act skips[5];
+  skips[0] = Act{h->blocks[h->layer_last_block[2]].out, 256, nullptr, nullptr, 0};   // f4
+  skips[1] = Act{h->blocks[h->layer_last_block[1]].out, 128, nullptr, nullptr, 0};   // f3
+  skips[2] = Act{h->blocks[h->layer_last_block[0]].out, 64, nullptr, nullptr, 0};    // f2
+  skips[3] = bn_act(h, stem);                                                         // f1 = relu(bn1(conv1 x))
+  skips[4] = Act{nullptr, 0, nullptr, nullptr, 0};
+  Act xd = cur;   // f5
+  for (size_t i = 0; i < h->decs.size(); ++i) {
+    DecL& d = h->decs[i];
+    ConvL& c1 = h->convs[d.conv1];
+    ConvL& c2 = h->convs[d.conv2];
+    RET_IF(run_conv(h, c1, to_src(xd, 1), d.Cskip ? to_src(skips[i]) : null_src(), training, st));
+    RET_IF(run_conv(h, c2, to_src(bn_act(h, c1)), null_src(), training, st));
+    xd = bn_act(h, c2);
+  }
+  // head
+  vk_src hs = to_src(xd);
+  RET_IF(vk_head_fwd(dt, N, S, S, &hs, h->params + h->head_w_off, h->params + h->head_b_off, logits, st));
+  if (training) {
+    hipLaunchKernelGGL(k_inc_i64, dim3(1), dim3(64), 0, st, (int)h->bns.size(), h->nbt);
+    VK_CHECK_HIP(hipGetLastError());
+  }
+  return VK_OK;
+}
+
+extern "C" int vk_unet_loss(vk_unet* h, const float* logits, const float* target, float* loss_out, float grad_scale, float w_bce,
+                            float w_dice, void* stream) {
+  VK_CHECK_ARG(h && h->bound && logits && target && loss_out, "vk_unet_loss: plan not bound or null tensor");
+  const size_t count = (size_t)h->cfg.N * h->cfg.size * h->cfg.size;
+  float* dl = h->cfg.training ? (float*)(h->ws + h->off_dlogits) : nullptr;
+  return vk_bce_dice_loss(count, logits, target, (double*)(h->ws + h->off_loss_sums), loss_out, dl, grad_scale, w_bce, w_dice, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+namespace {
+
+// gradient wrt activated output (in c.g) -> gradient wrt z (in place); dgamma/dbeta accumulated
+int bn_relu_bwd_inplace(vk_unet* h, ConvL& c, hipStream_t st) {
+  BnL& b = h->bns[c.bn];
+  const size_t pixels = (size_t)h->cfg.N * c.Hout * c.Hout;
+  RET_IF(vk_bn_bwd_reduce(h->cfg.dtype, pixels, c.K, c.g, c.z, 1, b.scale, b.shift, nullptr, b.bsums, st));
+  RET_IF(vk_bn_bwd_coeffs(c.K, b.bsums, b.count, h->params + b.g_off, b.mean, b.invstd, h->grads + b.g_off, h->grads + b.b_off, b.coef, st));
+  return vk_bn_bwd_apply(h->cfg.dtype, pixels, c.K, c.g, c.z, 1, b.scale, b.shift, nullptr, b.coef, c.g, nullptr, 0, st);
+}
+
+int conv_wgrad(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, hipStream_t st) {
+  vk_conv_desc d = conv_desc(h, c, s0, s1);
+  return vk_conv_wgrad(&d, c.g, h->grads + c.w_off, st);
+}
+
+// dx = dgrad(dz of conv c) into y (and y1 for the channel split)
+int conv_dgrad(vk_unet* h, ConvL& c, void* y, void* y1, int split, int accumulate, hipStream_t st) {
+  vk_conv_desc d;
+  d.dtype = h->cfg.dtype;
+  d.N = h->cfg.N; d.H = c.Hout; d.W = c.Hout; d.Ho = c.Hin; d.Wo = c.Hin;
+  d.K = c.Cin; d.R = c.R; d.S = c.R; d.stride = c.stride; d.pad = c.pad; d.transposed = 1;
+  vk_src s;
+  s.ptr = c.g; s.C = c.K; s.up = 0; s.scale = nullptr; s.shift = nullptr; s.relu = 0;
+  d.src0 = s;
+  d.src1 = null_src();
+  return vk_conv_fwd(&d, dgrad_weights(h, c), y, y1, split, accumulate, nullptr, st);
+}
+
+int backward_decoder(vk_unet* h, int i, hipStream_t st) {
+  DecL& d = h->decs[i];
+  ConvL& c1 = h->convs[d.conv1];
+  ConvL& c2 = h->convs[d.conv2];
+  const int N = h->cfg.N;
+  ConvL& stem = h->convs[h->stem_conv];
+  // inputs of conv1 (same virtual tensors as in forward)
+  Act xprev, skip{nullptr, 0, nullptr, nullptr, 0};
+  void* g_prev;       // gradient buffer of the upsampled input (low resolution)
+  if (i == 0) {
+    BlockL& f5 = h->blocks[h->layer_last_block[3]];
+    xprev = Act{f5.out, 512, nullptr, nullptr, 0};
+    g_prev = f5.gout;
+  } else {
+    ConvL& pc2 = h->convs[h->decs[i - 1].conv2];
+    xprev = bn_act(h, pc2);
+    g_prev = pc2.g;
+  }
+  void* g_skip = nullptr;
+  if (i <= 2) {
+    BlockL& fb = h->blocks[h->layer_last_block[2 - i]];
+    skip = Act{fb.out, fb.C, nullptr, nullptr, 0};
+    g_skip = fb.gout;
+  } else if (i == 3) {
+    skip = bn_act(h, stem);
+    g_skip = stem.g;
+  }
+  // conv2 unit
+  RET_IF(bn_relu_bwd_inplace(h, c2, st));
+  RET_IF(conv_wgrad(h, c2, to_src(bn_act(h, c1)), null_src(), st));
+  RET_IF(conv_dgrad(h, c2, c1.g, nullptr, 0, 0, st));
+  // conv1 unit
+  RET_IF(bn_relu_bwd_inplace(h, c1, st));
+  RET_IF(conv_wgrad(h, c1, to_src(xprev, 1), d.Cskip ? to_src(skip) : null_src(), st));
+  void* dup = h->ws + h->off_dup;
+  if (d.Cskip) RET_IF(conv_dgrad(h, c1, dup, g_skip, d.Cup, 0, st));
+  else RET_IF(conv_dgrad(h, c1, dup, nullptr, 0, 0, st));
+  return vk_upsample2x_bwd(h->cfg.dtype, N, d.H, d.H, d.Cup, dup, g_prev, 0, st);
+}
+
+int backward_block(vk_unet* h, int bi, hipStream_t st) {
+  BlockL& k = h->blocks[bi];
+  ConvL& c1 = h->convs[k.conv1];
+  ConvL& c2 = h->convs[k.conv2];
+  BnL& b2 = h->bns[c2.bn];
+  const vk_dtype dt = h->cfg.dtype;
+  const size_t pixels = (size_t)h->cfg.N * k.Hout * k.Hout;
+  // block input (materialised) and its gradient buffer
+  Act xin;
+  void* gin;
+  if (bi == 0) {
+    xin = Act{h->ws + h->off_pool, 64, nullptr, nullptr, 0};
+    gin = h->ws + h->off_gpool;
+  } else {
+    BlockL& pb = h->blocks[bi - 1];
+    xin = Act{pb.out, pb.C, nullptr, nullptr, 0};
+    gin = pb.gout;
+  }
+  // tail: out = relu(bn2(z2) + shortcut);  g = gout * (out > 0)
+  RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.bsums, st));
+  RET_IF(vk_bn_bwd_coeffs(k.C, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd, h->grads + b2.g_off, h->grads + b2.b_off, b2.coef, st));
+  if (k.convd < 0) {
+    // identity shortcut: gin (+)= g
+    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.coef, c2.g, gin, k.in_has_grad_first ? 1 : 0, st));
+  } else {
+    ConvL& cd = h->convs[k.convd];
+    BnL& bd = h->bns[cd.bn];
+    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.coef, c2.g, nullptr, 0, st));
+    RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, cd.z, 2, nullptr, nullptr, k.out, bd.bsums, st));
+    RET_IF(vk_bn_bwd_coeffs(k.C, bd.bsums, bd.count, h->params + bd.g_off, bd.mean, bd.invstd, h->grads + bd.g_off, h->grads + bd.b_off, bd.coef, st));
+    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, cd.z, 2, nullptr, nullptr, k.out, bd.coef, cd.g, nullptr, 0, st));
+  }
+  // conv2
+  RET_IF(conv_wgrad(h, c2, to_src(bn_act(h, c1)), null_src(), st));
+  RET_IF(conv_dgrad(h, c2, c1.g, nullptr, 0, 0, st));
+  // conv1
+  RET_IF(bn_relu_bwd_inplace(h, c1, st));
+  RET_IF(conv_wgrad(h, c1, to_src(xin), null_src(), st));
+  // gin was written by the identity shortcut above or (downsample blocks) by the decoder skip gradient
+  RET_IF(conv_dgrad(h, c1, gin, nullptr, 0, 1, st));
+  if (k.convd >= 0) {
+    ConvL& cd = h->convs[k.convd];
+    RET_IF(conv_wgrad(h, cd, to_src(xin), null_src(), st));
+    RET_IF(conv_dgrad(h, cd, gin, nullptr, 0, 1, st));
+  }
+  return VK_OK;
+}
+
+int backward_stem(vk_unet* h, hipStream_t st) {
+  const int N = h->cfg.N, S = h->cfg.size;
+  ConvL& stem = h->convs[h->stem_conv];
+  // stem.g holds the skip gradient of f1 (from decoder block 3); add the maxpool path
+  RET_IF(vk_maxpool_bwd(h->cfg.dtype, N, S / 2, S / 2, 64, h->ws + h->off_gpool, (const uint8_t*)(h->ws + h->off_argmax), stem.g, st));
+  RET_IF(bn_relu_bwd_inplace(h, stem, st));
+  return vk_stem_wgrad(h->cfg.dtype, N, S, S, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, st);
+}
+
+int backward_stage(vk_unet* h, const float* dlogits, int stage, hipStream_t st) {
+  const int N = h->cfg.N, S = h->cfg.size;
+  switch (stage) {
+    case 0: {
+      VK_CHECK_HIP(hipMemsetAsync(h->ws + h->off_bsums, 0, h->stats_bytes, st));
+      ConvL& last = h->convs[h->decs[4].conv2];
+      vk_src hs = to_src(bn_act(h, last));
+      RET_IF(vk_head_bwd(h->cfg.dtype, N, S, S, &hs, h->params + h->head_w_off, dlogits ? dlogits : (const float*)(h->ws + h->off_dlogits), last.g,
+                         h->grads + h->head_w_off, h->grads + h->head_b_off, st));
+      RET_IF(backward_decoder(h, 4, st));
+      RET_IF(backward_decoder(h, 3, st));
+      return backward_decoder(h, 2, st);
+    }
+    case 1: return backward_decoder(h, 1, st);
+    case 2: return backward_decoder(h, 0, st);
+    case 3: return backward_block(h, 15, st);
+    case 4: return backward_block(h, 14, st);
+    case 5: return backward_block(h, 13, st);
+    case 6:
+      for (int b = 12; b >= 10; --b) RET_IF(backward_block(h, b, st));
+      return VK_OK;
+    case 7:
+      for (int b = 9; b >= 7; --b) RET_IF(backward_block(h, b, st));
+      return VK_OK;
+    case 8:
+      for (int b = 6; b >= 3; --b) RET_IF(backward_block(h, b, st));
+      return VK_OK;
+    case 9:
+      for (int b = 2; b >= 0; --b) RET_IF(backward_block(h, b, st));
+      return backward_stem(h, st);
+  }
+  vkh::set_error("vk_unet_backward: bad stage %d", stage);
+  return VK_ERR_ARG;
+}
+
+}  // namespace
+
+extern "C" int vk_unet_backward(vk_unet* h, const float* dlogits, int stage_begin, int stage_end, void* stream) {
+  VK_CHECK_ARG(h && h->bound && h->cfg.training && h->grads, "vk_unet_backward: needs a bound training plan");
+  VK_CHECK_ARG(stage_begin >= 0 && stage_end <= (int)h->buckets.size() && stage_begin <= stage_end, "vk_unet_backward: bad stage range");
+  for (int s = stage_begin; s < stage_end; ++s) RET_IF(backward_stage(h, dlogits, s, (hipStream_t)stream));
+  return VK_OK;
+}

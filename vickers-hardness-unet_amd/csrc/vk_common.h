@@ -1,0 +1,200 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the U-Net path.
+// Everything here is written for wave64 / MFMA / LDS directly; there is no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vk_unet.h"
+
+namespace vk {
+
+// ---------------------------------------------------------------- element types
+struct bf16_t { uint16_t v; };   // storage-only wrappers: arithmetic is always done in fp32
+struct f16_t  { uint16_t v; };
+
+typedef __attribute__((ext_vector_type(8))) __bf16   bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float    f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((ext_vector_type(4))) short    s16x4_t;
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int kBytes = 4;
+  static constexpr int kVec = 4;     // elements per 16-byte vector
+  static constexpr vk_dtype kDtype = VK_F32;
+};
+template <> struct ElemTraits<bf16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr int kVec = 8;
+  static constexpr vk_dtype kDtype = VK_BF16;
+};
+template <> struct ElemTraits<f16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr int kVec = 8;
+  static constexpr vk_dtype kDtype = VK_F16;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  // plain cast => v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even, NaN stays NaN)
+  __bf16 h = (__bf16)f;
+  return (uint32_t)__builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t b) {
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)b);
+}
+__device__ __forceinline__ uint32_t f32_to_f16_bits(float f) {
+  _Float16 h = (_Float16)f;
+  return (uint32_t)__builtin_bit_cast(uint16_t, h);
+}
+
+// scalar load / store of one element as fp32
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf16_bits_to_f32(p->v); }
+template <> __device__ __forceinline__ float ld1<f16_t>(const f16_t* p) { return f16_bits_to_f32(p->v); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float f);
+template <> __device__ __forceinline__ void st1<float>(float* p, float f) { *p = f; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float f) { p->v = (uint16_t)f32_to_bf16_bits(f); }
+template <> __device__ __forceinline__ void st1<f16_t>(f16_t* p, float f) { p->v = (uint16_t)f32_to_f16_bits(f); }
+
+// value after a round trip through T (what is actually stored)
+template <typename T> __device__ __forceinline__ float round_to(float f);
+template <> __device__ __forceinline__ float round_to<float>(float f) { return f; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
+template <> __device__ __forceinline__ float round_to<f16_t>(float f) { return f16_bits_to_f32(f32_to_f16_bits(f)); }
+
+// 16-byte vector <-> kVec floats
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static __device__ __forceinline__ void unpack(u32x4_t v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, v[i]);
+  }
+  static __device__ __forceinline__ u32x4_t pack(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(uint32_t, f[i]);
+    return v;
+  }
+};
+template <> struct Vec16<bf16_t> {
+  static __device__ __forceinline__ void unpack(u32x4_t v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+      f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ u32x4_t pack(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = f32_to_bf16_bits(f[2 * i]) | (f32_to_bf16_bits(f[2 * i + 1]) << 16);
+    return v;
+  }
+};
+template <> struct Vec16<f16_t> {
+  static __device__ __forceinline__ void unpack(u32x4_t v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = f16_bits_to_f32(v[i] & 0xffffu);
+      f[2 * i + 1] = f16_bits_to_f32(v[i] >> 16);
+    }
+  }
+  static __device__ __forceinline__ u32x4_t pack(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = f32_to_f16_bits(f[2 * i]) | (f32_to_f16_bits(f[2 * i + 1]) << 16);
+    return v;
+  }
+};
+
+// ---------------------------------------------------------------- MFMA wrappers (16x16 output tile)
+// D[row = (lane>>4)*4 + reg][col = lane&15] += A[row][k] * B[k][col]
+//   16-bit: lane holds A[lane&15][8*(lane>>4)+j], B[8*(lane>>4)+j][lane&15], j=0..7  (K = 32)
+//   fp32  : lane holds A[lane&15][lane>>4],       B[lane>>4][lane&15]               (K = 4)
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ f32x4_t run(u32x4_t a, u32x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<f16_t> {
+  static __device__ __forceinline__ f32x4_t run(u32x4_t a, u32x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // a,b hold 4 consecutive k per lane; k is permuted consistently between A and B (the sum over k
+  // does not care), so one ds_read_b128 feeds four 16x16x4 MFMAs.
+  static __device__ __forceinline__ f32x4_t run(u32x4_t a, u32x4_t b, f32x4_t c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[e]), __builtin_bit_cast(float, b[e]), c, 0, 0, 0);
+    return c;
+  }
+};
+
+// ---------------------------------------------------------------- buffer (SRD) loads with free bounds check
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4_t buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+}
+static constexpr uint32_t kOOB = 0x80000000u;   // any tensor on this path is < 2 GiB (checked on the host)
+
+// ---------------------------------------------------------------- fast division by a runtime constant (n < 2^31)
+struct FastDiv {
+  uint32_t mul, shr, div;
+};
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return d.div == 1 ? n : (__umulhi(n, d.mul) >> d.shr); }
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace vk
+
+// host-side helpers -----------------------------------------------------------------------------
+namespace vkh {
+inline vk::FastDiv make_fastdiv(uint32_t d) {
+  vk::FastDiv f;
+  f.div = d;
+  if (d <= 1) { f.mul = 0; f.shr = 0; f.div = 1; return f; }
+  uint32_t lg = 0;
+  while ((1u << lg) < d) ++lg;
+  uint32_t p = 31 + lg;
+  f.mul = (uint32_t)(((1ull << p) + d - 1) / d);
+  f.shr = p - 32;
+  return f;
+}
+void set_error(const char* fmt, ...);
+}  // namespace vkh
+
+#define VK_CHECK_ARG(cond, ...)                \
+  do {                                         \
+    if (!(cond)) {                             \
+      vkh::set_error(__VA_ARGS__);             \
+      return VK_ERR_ARG;                       \
+    }                                          \
+  } while (0)
+
+#define VK_CHECK_HIP(expr)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      vkh::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return (int)e_;                                                                   \
+    }                                                                                   \
+  } while (0)
