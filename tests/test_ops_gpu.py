@@ -21,13 +21,31 @@ def dev():
     return torch.device("cuda:0")
 
 
+KEEP = []     # device tensors must outlive the asynchronous launches that read them
+
+
+@pytest.fixture(autouse=True)
+def _keepalive():
+    KEEP.clear()
+    yield
+    torch.cuda.synchronize()
+    KEEP.clear()
+
+
+def D(t):
+    """CPU tensor -> device tensor that stays alive until the end of the test."""
+    t = t.to(dev())
+    KEEP.append(t)
+    return t
+
+
 def tol(dt, ref):
     scale = ref.abs().max().item() + 1e-6
     return (2e-5 if dt == torch.float32 else 1.2e-2) * scale
 
 
-def to_nhwc(x, dt):      # NCHW fp32 cpu -> NHWC dt cuda
-    return x.permute(0, 2, 3, 1).contiguous().to(dt).to(dev())
+def to_nhwc(x, dt):      # NCHW fp32 cpu -> NHWC dt cuda (kept alive)
+    return D(x.permute(0, 2, 3, 1).contiguous().to(dt))
 
 
 def from_nhwc(t):        # NHWC cuda -> NCHW fp32 cpu
@@ -83,13 +101,13 @@ def test_conv_fwd(case, dtn):
     x = gen(N, Cc, H, H, seed=1)
     w = gen(K, Cc, R, R, seed=2, scale=(2.0 / (Cc * R * R)) ** 0.5)
     xd = to_nhwc(x, dt)
-    wd = w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev())
+    wd = D(w.permute(0, 2, 3, 1).contiguous().to(dt))
     v = rnd(x, dt)
     sc = sh = None
     if affine:
         sc_c = 0.5 + torch.rand(Cc, generator=torch.Generator().manual_seed(3))
         sh_c = gen(Cc, seed=4, scale=0.3)
-        sc, sh = sc_c.to(dev()), sh_c.to(dev())
+        sc, sh = D(sc_c), D(sh_c)
         v = rnd(torch.relu(v * sc_c.view(1, -1, 1, 1) + sh_c.view(1, -1, 1, 1)), dt)
     ref = F.conv2d(v.double(), rnd(w, dt).double(), stride=stride, padding=pad).float()
     y = torch.full((N, Ho, Ho, K), float("nan"), dtype=dt, device=dev())
@@ -130,8 +148,8 @@ def test_conv_fwd_upsample_concat(shape, dtn):
         s1 = mk_src(skd, Cskip)
     ref = F.conv2d(v.double(), rnd(w, dt).double(), padding=1).float()
     lod = to_nhwc(lo, dt)
-    wd = w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev())
-    scd, shd = sc_c.to(dev()), sh_c.to(dev())
+    wd = D(w.permute(0, 2, 3, 1).contiguous().to(dt))
+    scd, shd = D(sc_c), D(sh_c)
     y = torch.empty((N, H, H, K), dtype=dt, device=dev())
     d = conv_desc(dt, N, H, H, H, H, K, 3, 1, 1, 0, mk_src(lod, Cup, 1, scd, shd, 1), s1)
     vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wd.data_ptr(), y.data_ptr(), None, 0, 0, None, st()))
@@ -146,14 +164,14 @@ def test_stem_fwd(dtn):
     N, S = 2, 64
     x = gen(N, 3, S, S, seed=11)
     w = gen(64, 3, 7, 7, seed=12, scale=0.1)
-    xd = x.to(dev())
+    xd = D(x)
     x4 = torch.empty((N, S, S, 4), dtype=dt, device=dev())
     vk._lib.check(vk.lib().vk_input_transform(L_.dtype_code(dt), N, S, S, xd.data_ptr(), x4.data_ptr(), st()))
     assert torch.equal(x4[..., :3].float().cpu(), rnd(x, dt).permute(0, 2, 3, 1))
     assert (x4[..., 3] == 0).all()
     wp = torch.zeros(64, 7, 8, 4)
     wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
-    wpd = wp.reshape(64, 7, 32).to(dt).to(dev())
+    wpd = D(wp.reshape(64, 7, 32).to(dt))
     y = torch.empty((N, S // 2, S // 2, 64), dtype=dt, device=dev())
     stats = torch.zeros(128, dtype=torch.float64, device=dev())
     vk._lib.check(vk.lib().vk_stem_fwd(L_.dtype_code(dt), N, S, S, x4.data_ptr(), wpd.data_ptr(), y.data_ptr(), stats.data_ptr(), st()))
@@ -186,7 +204,7 @@ def test_conv_dgrad(case, dtn):
     out.backward(rnd(dz, dt).double())
     ref = xin.grad.float()
     dzd = to_nhwc(dz, dt)
-    wt = w.permute(1, 2, 3, 0).contiguous().to(dt).to(dev())     # [C][R][S][K]
+    wt = D(w.permute(1, 2, 3, 0).contiguous().to(dt))     # [C][R][S][K]
     dx = torch.full((N, H, H, Cc), float("nan"), dtype=dt, device=dev())
     d = conv_desc(dt, N, Ho, Ho, H, H, Cc, R, stride, pad, 1, mk_src(dzd, K))
     vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wt.data_ptr(), dx.data_ptr(), None, 0, 0, None, st()))
@@ -212,7 +230,7 @@ def test_conv_dgrad_split(dtn):
     F.conv2d(xin, rnd(w, dt).double(), padding=1).backward(rnd(dz, dt).double())
     ref = xin.grad.float()
     dzd = to_nhwc(dz, dt)
-    wt = w.permute(1, 2, 3, 0).contiguous().to(dt).to(dev())
+    wt = D(w.permute(1, 2, 3, 0).contiguous().to(dt))
     y0 = torch.empty((N, H, H, Cup), dtype=dt, device=dev())
     y1 = torch.empty((N, H, H, Cskip), dtype=dt, device=dev())
     d = conv_desc(dt, N, H, H, H, H, Cup + Cskip, 3, 1, 1, 1, mk_src(dzd, K))
@@ -251,7 +269,7 @@ def test_conv_wgrad(case, dtn):
     ref = wv.grad.float()
     xd, dzd = to_nhwc(x, dt), to_nhwc(dz, dt)
     dw = torch.zeros(K, R, R, Cc, dtype=torch.float32, device=dev())
-    d = conv_desc(dt, N, H, H, Ho, Ho, K, R, stride, pad, 0, mk_src(xd, Cc, 0, sc_c.to(dev()), sh_c.to(dev()), 1))
+    d = conv_desc(dt, N, H, H, Ho, Ho, K, R, stride, pad, 0, mk_src(xd, Cc, 0, D(sc_c), D(sh_c), 1))
     vk._lib.check(vk.lib().vk_conv_wgrad(C.byref(d), dzd.data_ptr(), dw.data_ptr(), st()))
     torch.cuda.synchronize()
     got = dw.cpu().permute(0, 3, 1, 2)
@@ -290,7 +308,7 @@ def test_stem_wgrad(dtn):
     F.conv2d(rnd(x, dt).double(), wv, stride=2, padding=3).backward(rnd(dz, dt).double())
     ref = wv.grad.float()
     x4 = torch.zeros((N, S, S, 4), dtype=dt, device=dev())
-    x4[..., :3] = x.permute(0, 2, 3, 1).to(dt).to(dev())
+    x4[..., :3] = D(x.permute(0, 2, 3, 1).to(dt))
     dzd = to_nhwc(dz, dt)
     dw = torch.zeros(64, 7, 7, 3, dtype=torch.float32, device=dev())
     vk._lib.check(vk.lib().vk_stem_wgrad(L_.dtype_code(dt), N, S, S, x4.data_ptr(), dzd.data_ptr(), dw.data_ptr(), st()))
@@ -304,9 +322,9 @@ def test_bn_finalize_train_and_eval():
     Cc, cnt = 64, 1000.0
     g = torch.Generator().manual_seed(71)
     data = torch.randn(1000, Cc, generator=g, dtype=torch.float64) * 2 + 0.5
-    stats = torch.cat([data.sum(0), (data * data).sum(0)]).to(dev())
-    gamma = (0.5 + torch.rand(Cc, generator=g)).to(dev())
-    beta = torch.randn(Cc, generator=g).to(dev())
+    stats = D(torch.cat([data.sum(0), (data * data).sum(0)]))
+    gamma = D(0.5 + torch.rand(Cc, generator=g))
+    beta = D(torch.randn(Cc, generator=g))
     rm, rv = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())
     scale, shift, mean, invstd = (torch.empty(Cc, device=dev()) for _ in range(4))
     vk._lib.check(vk.lib().vk_bn_finalize(Cc, 1, stats.data_ptr(), cnt, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
@@ -337,8 +355,8 @@ def test_bn_relu_maxpool_and_bwd(dtn):
     zd = to_nhwc(z, dt)
     pooled = torch.empty((N, H // 2, H // 2, Cc), dtype=dt, device=dev())
     am = torch.empty((N, H // 2, H // 2, Cc), dtype=torch.uint8, device=dev())
-    vk._lib.check(vk.lib().vk_bn_relu_maxpool(L_.dtype_code(dt), N, H, H, Cc, zd.data_ptr(), sc_c.to(dev()).data_ptr(),
-                                              sh_c.to(dev()).data_ptr(), pooled.data_ptr(), am.data_ptr(), st()))
+    vk._lib.check(vk.lib().vk_bn_relu_maxpool(L_.dtype_code(dt), N, H, H, Cc, zd.data_ptr(), D(sc_c).data_ptr(),
+                                              D(sh_c).data_ptr(), pooled.data_ptr(), am.data_ptr(), st()))
     a = torch.relu(rnd(z, dt) * sc_c.view(1, -1, 1, 1) + sh_c.view(1, -1, 1, 1)).requires_grad_(True)
     ref = F.max_pool2d(a, 3, 2, 1)
     assert (from_nhwc(pooled) - ref.detach()).abs().max().item() <= tol(dt, ref.detach())
@@ -365,7 +383,7 @@ def test_bn_add_relu(dtn, down):
     res = rnd(r, dt) * v(rsc) + v(rsh) if down else rnd(r, dt)
     ref = torch.relu(rnd(z, dt) * v(sc) + v(sh) + res)
     out = torch.empty((N, H, H, Cc), dtype=dt, device=dev())
-    scd, shd, rscd, rshd = (t.to(dev()) for t in (sc, sh, rsc, rsh))
+    scd, shd, rscd, rshd = (D(t) for t in (sc, sh, rsc, rsh))
     vk._lib.check(vk.lib().vk_bn_add_relu(L_.dtype_code(dt), N * H * H, Cc, to_nhwc(z, dt).data_ptr(), scd.data_ptr(), shd.data_ptr(),
                                           to_nhwc(r, dt).data_ptr(), rscd.data_ptr() if down else None,
                                           rshd.data_ptr() if down else None, out.data_ptr(), st()))
@@ -395,8 +413,8 @@ def test_bn_relu_backward(dtn, mask_mode):
     mean = z.double().mean(dim=(0, 2, 3))
     var = z.double().var(dim=(0, 2, 3), unbiased=False)
     invstd = 1.0 / torch.sqrt(var + 1e-5)
-    scale = (gamma.double() * invstd).float().to(dev())
-    shift = (beta.double() - mean * gamma.double() * invstd).float().to(dev())
+    scale = D((gamma.double() * invstd).float())
+    shift = D((beta.double() - mean * gamma.double() * invstd).float())
     sums = torch.zeros(2 * Cc, dtype=torch.float64, device=dev())
     zd, dyd = to_nhwc(z, dt), to_nhwc(dy, dt)
     outd = to_nhwc(out.detach().float(), dt)
@@ -405,8 +423,8 @@ def test_bn_relu_backward(dtn, mask_mode):
                                             shift.data_ptr(), outd.data_ptr(), sums.data_ptr(), st()))
     dgam, dbet = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
     coef = torch.empty(3 * Cc, device=dev())
-    vk._lib.check(vk.lib().vk_bn_bwd_coeffs(Cc, sums.data_ptr(), cnt, gamma.to(dev()).data_ptr(), mean.float().to(dev()).data_ptr(),
-                                            invstd.float().to(dev()).data_ptr(), dgam.data_ptr(), dbet.data_ptr(), coef.data_ptr(), st()))
+    vk._lib.check(vk.lib().vk_bn_bwd_coeffs(Cc, sums.data_ptr(), cnt, D(gamma).data_ptr(), D(mean.float()).data_ptr(),
+                                            D(invstd.float()).data_ptr(), dgam.data_ptr(), dbet.data_ptr(), coef.data_ptr(), st()))
     dz = torch.empty_like(zd)
     gout = torch.zeros_like(zd)
     vk._lib.check(vk.lib().vk_bn_bwd_apply(code, N * H * H, Cc, dyd.data_ptr(), zd.data_ptr(), mask_mode, scale.data_ptr(),
@@ -451,17 +469,17 @@ def test_head_fwd_bwd(dtn):
     dl = gen(N, 1, H, H, seed=124)
     ref.backward(dl.double())
     zd = to_nhwc(z, dt)
-    w9 = w[0].permute(1, 2, 0).contiguous().to(dev())       # [3][3][16]
-    src = mk_src(zd, 16, 0, sc.to(dev()), sh.to(dev()), 1)
+    w9 = D(w[0].permute(1, 2, 0).contiguous())       # [3][3][16]
+    src = mk_src(zd, 16, 0, D(sc), D(sh), 1)
     logits = torch.empty(N, 1, H, H, device=dev())
-    bd = b.to(dev())
+    bd = D(b)
     vk._lib.check(vk.lib().vk_head_fwd(L_.dtype_code(dt), N, H, H, C.byref(src), w9.data_ptr(), bd.data_ptr(), logits.data_ptr(), st()))
     torch.cuda.synchronize()
     assert (logits.cpu() - ref.detach().float()).abs().max().item() <= 1e-4 * ref.abs().max().item()
     dy = torch.empty((N, H, H, 16), dtype=dt, device=dev())
     dw = torch.zeros(3, 3, 16, device=dev())
     db = torch.zeros(1, device=dev())
-    vk._lib.check(vk.lib().vk_head_bwd(L_.dtype_code(dt), N, H, H, C.byref(src), w9.data_ptr(), dl.to(dev()).data_ptr(), dy.data_ptr(),
+    vk._lib.check(vk.lib().vk_head_bwd(L_.dtype_code(dt), N, H, H, C.byref(src), w9.data_ptr(), D(dl).data_ptr(), dy.data_ptr(),
                                        dw.data_ptr(), db.data_ptr(), st()))
     torch.cuda.synchronize()
     assert (from_nhwc(dy) - a.grad.float()).abs().max().item() <= tol(dt, a.grad.float())
@@ -477,7 +495,7 @@ def test_bce_dice_loss(wb, wd):
     y = (torch.rand(3, 1, 32, 32, generator=g) > 0.8).float()
     ref = wb * F.binary_cross_entropy_with_logits(x, y) + wd * O.DiceLoss()(x, y)
     ref.backward()
-    xd, yd = x.detach().to(dev()), y.to(dev())
+    xd, yd = D(x.detach()), D(y)
     sums = torch.empty(8, dtype=torch.float64, device=dev())
     out = torch.empty(4, device=dev())
     dl = torch.empty_like(xd)
@@ -499,13 +517,13 @@ def test_adamw_matches_torch():
     p0 = torch.randn(n, generator=g)
     pr = torch.nn.Parameter(p0.clone())
     opt = torch.optim.AdamW([pr], lr=5e-5, weight_decay=1e-4)
-    pd = p0.clone().to(dev())
+    pd = D(p0.clone())
     m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
     for step in range(1, 4):
         gr = torch.randn(n, generator=g)
         pr.grad = gr.clone()
         opt.step()
-        gd = gr.to(dev())
+        gd = D(gr)
         vk._lib.check(vk.lib().vk_adamw_step(n, pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), 5e-5, 0.9, 0.999, 1e-8, 1e-4,
                                              step, 1.0, None, None, 0, st()))
     torch.cuda.synchronize()

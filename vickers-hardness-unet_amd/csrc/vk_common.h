@@ -36,7 +36,11 @@ template <> struct ElemTraits<f16_t> {
   static constexpr vk_dtype kDtype = VK_F16;
 };
 
-__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+// NOTE: never __builtin_bit_cast an ext-vector ELEMENT (v[i]) directly: hipcc (ROCm 7.2) takes the address
+// of the whole vector and silently returns element 0.  Go through these by-value helpers.
+__device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return as_f32(b << 16); }
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
   // plain cast => v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even, NaN stays NaN)
   __bf16 h = (__bf16)f;
@@ -71,12 +75,12 @@ template <typename T> struct Vec16;
 template <> struct Vec16<float> {
   static __device__ __forceinline__ void unpack(u32x4_t v, float* f) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, v[i]);
+    for (int i = 0; i < 4; ++i) f[i] = as_f32(v[i]);
   }
   static __device__ __forceinline__ u32x4_t pack(const float* f) {
     u32x4_t v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(uint32_t, f[i]);
+    for (int i = 0; i < 4; ++i) v[i] = as_u32(f[i]);
     return v;
   }
 };
@@ -84,8 +88,8 @@ template <> struct Vec16<bf16_t> {
   static __device__ __forceinline__ void unpack(u32x4_t v, float* f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
-      f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+      f[2 * i] = as_f32(v[i] << 16);
+      f[2 * i + 1] = as_f32(v[i] & 0xffff0000u);
     }
   }
   static __device__ __forceinline__ u32x4_t pack(const float* f) {
@@ -132,7 +136,7 @@ template <> struct Mma<float> {
   static __device__ __forceinline__ f32x4_t run(u32x4_t a, u32x4_t b, f32x4_t c) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[e]), __builtin_bit_cast(float, b[e]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f32(a[e]), as_f32(b[e]), c, 0, 0, 0);
     return c;
   }
 };
