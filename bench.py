@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of one full training step (forward + BCE/Dice + backward + AdamW
+[+ gradient all-reduce]) of the ResNet-34 U-Net on synthetic 512x512 batches, bs=32 per GPU, bf16
+(BASELINE.json configs[2]; configs[3] when launched under torchrun with N ranks).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--size 512] [--dtype bf16]
+                    [--mode train|infer] [--no-cpu-baseline]
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     : the dominant kernel family (most GPU time in the profiled steps), its algorithmic
+                 FLOP/s (or B/s) from live HIP-event timing on the launch stream vs the gfx950 peak
+  cpu_baseline : the oracle (torch CPU restatement of the reference path) timed on this host's cores
+                 on a bounded sample (rank 0, N=1 only) — a reported baseline, never the target.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+_T0 = time.perf_counter()
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_MFMA_16B = 2.5e15     # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
+PEAK_MFMA_F32 = 157.3e12
+PEAK_HBM = 8.0e12
+
+FWD_GFLOP_PER_IMG_512 = 62.512
+TRAIN_GFLOP_PER_IMG_512 = 186.30
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    vk = importlib.import_module("vickers-hardness-unet_amd")
+    from oracle import unet_oracle as O      # synthetic data generator + (rank 0) CPU baseline only
+
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    N, S = args.batch, args.size
+
+    O.set_seed(42)
+    model = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev)
+    opt = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
+    if world > 1:
+        vk.make_data_parallel(model, opt)
+    x, y = O.synthetic_batch(N, S, seed=1234 + rank)      # rank r owns images [r*N, (r+1)*N)
+    x, y = x.to(dev), y.to(dev)
+    _log(f"rank {rank}/{world}: model + data resident on {torch.cuda.get_device_name(dev)}")
+
+    if args.mode == "train":
+        model.train()
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = model.loss_and_backward(x, y, dtype=dtype)
+            opt.step()
+            return out
+    else:
+        model.eval()
+        model.compute_dtype = dtype
+
+        def step():
+            with torch.no_grad():
+                return model(x)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    for i in range(args.warmup):
+        out = step()
+        if i == 0:
+            torch.cuda.synchronize()
+            _log("first step done")
+    torch.cuda.synchronize()
+    _log("warm-up done")
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _log(f"timed region: {dt / args.steps * 1e3:.2f} ms/step")
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    last = [float(v) for v in out.flatten()[:3].tolist()] if args.mode == "train" else None
+
+    # ---- per-kernel-family timing with HIP events on the launch stream (a few extra, untimed-for-value steps)
+    roof = None
+    table = {}
+    if rank == 0:
+        L = vk.lib()
+        L.vk_prof_enable(1)
+        for _ in range(args.prof_steps):
+            step()
+        torch.cuda.synchronize()
+        L.vk_prof_enable(0)
+        table = vk._lib.prof_collect()
+        _log("event profile collected")
+        if table:
+            dom = max(table.items(), key=lambda kv: kv[1]["ms"])
+            tag, r = dom
+            per_launch_ms = r["ms"] / r["n"]
+            if r["flops"] > 0 and ("igemm" in tag or "wgrad" in tag or "stem" in tag):
+                peak = PEAK_MFMA_F32 if "f32" in tag else PEAK_MFMA_16B
+                ach = r["flops"] / (r["ms"] * 1e-3)
+                roof = {"kernel": tag, "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": r["n"] / args.prof_steps,
+                        "avg_launch_ms": round(per_launch_ms, 4)}
+            else:
+                ach = r["bytes"] / (r["ms"] * 1e-3)
+                roof = {"kernel": tag, "bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM, 4), "traffic": None, "launches_per_step": r["n"] / args.prof_steps,
+                        "avg_launch_ms": round(per_launch_ms, 4)}
+            tot = sum(v["ms"] for v in table.values())
+            roof["share_of_gpu_time"] = round(r["ms"] / tot, 3)
+            roof["all_kernels_ms_per_step"] = {k: round(v["ms"] / args.prof_steps, 3) for k, v in
+                                               sorted(table.items(), key=lambda kv: -kv[1]["ms"])}
+
+    # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, single-GPU runs only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = _usable_cores()
+        torch.set_num_threads(cores)
+        _log(f"cpu baseline on {cores} threads ...")
+        O.set_seed(42)
+        ref = O.build_model()
+        bs = 2
+        xc, yc = O.synthetic_batch(bs, S, seed=1234)
+        if args.mode == "train":
+            ref.train()
+            ropt = torch.optim.AdamW(ref.parameters(), lr=5e-5, weight_decay=1e-4)
+            O.train_steps(ref, ropt, [(xc, yc)])                  # warm-up
+            t1 = time.perf_counter()
+            nst = 2
+            O.train_steps(ref, ropt, [(xc, yc)] * nst)
+            cdt = time.perf_counter() - t1
+            sample = f"{nst} fp32 train steps (fwd+loss+bwd+AdamW, per-step loss.item()) at bs={bs}, {S}x{S}, after 1 warm-up"
+        else:
+            ref.eval()
+            with torch.no_grad():
+                ref(xc)
+                t1 = time.perf_counter()
+                nst = 3
+                for _ in range(nst):
+                    ref(xc)
+                cdt = time.perf_counter() - t1
+            sample = f"{nst} fp32 eval forwards at bs={bs}, {S}x{S}, after 1 warm-up"
+        _log(f"cpu baseline done: {cdt / nst:.2f} s/step")
+        cpu = {"value": round(bs * nst / cdt, 3), "unit": "images/s", "cores": cores, "kind": "port", "sample": sample,
+               "cpu_model": _cpu_model()}
+
+    if rank == 0:
+        ips = world * N * args.steps / dt
+        rec = {
+            "metric": ("512x512 images/sec (train fwd+bwd)" if args.mode == "train" else "512x512 images/sec (eval fwd)")
+            if S == 512 else f"{S}x{S} images/sec ({args.mode})",
+            "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"unet_r34_{S} {args.dtype} {'train fwd+loss+bwd+AdamW' if args.mode == 'train' else 'eval forward'}, "
+                                   f"bs={N}/GPU, BCE+Dice, synthetic {S}x{S} (BASELINE.json configs[{2 if args.mode == 'train' else 1}])",
+                       "global_batch": world * N, "image_size": S,
+                       "parallelism": f"dp{world} (RCCL all-reduce of fp32 gradients, 10 buckets overlapped with backward)" if world > 1 else "single GPU"},
+            "conv_tflops": round((TRAIN_GFLOP_PER_IMG_512 if args.mode == "train" else FWD_GFLOP_PER_IMG_512) * (S / 512) ** 2 * ips / 1e3, 2),
+            "last_loss": last,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def _usable_cores():
+    """Threads we may actually run: affinity, capped by the cgroup CPU quota and by the 16-core share of a
+    one-GPU box (oversubscribing OpenMP threads makes the CPU leg crawl)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

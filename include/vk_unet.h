@@ -45,6 +45,13 @@ const char* vk_last_error_string(void);
 /* 1 if the code object for gfx950 is present in this build (always true for a product build) */
 int vk_has_gfx950_code(void);
 
+/* Per-launch timing (off by default): while enabled every launch made through this library is bracketed
+ * by two hipEvents on its own stream.  vk_prof_collect synchronises those events and writes one line per
+ * kernel family into buf: "tag count total_ms total_algorithmic_flops total_algorithmic_bytes\n";
+ * returns the number of bytes written (or <0).  Used by bench.py for the live roofline figure. */
+int vk_prof_enable(int on);
+int vk_prof_collect(char* buf, size_t buflen);
+
 /* ------------------------------------------------------------------------------------------------
  * Operator level (used by the engine below and by the per-kernel parity tests)
  * ---------------------------------------------------------------------------------------------- */

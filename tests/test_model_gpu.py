@@ -140,31 +140,50 @@ def test_fused_and_autograd_paths_agree(pair):
     assert (model.flat_grads - g1).abs().max().item() <= 1e-4 * denom     # atomics order only
 
 
-def test_bf16_training_step_close_to_fp32_oracle(pair):
-    """bf16 plan (what autocast selects): loss within 2 %, gradients aligned (cosine > 0.98 per large tensor)."""
+def test_bf16_training_step_tracks_reference_mixed_precision(pair):
+    """bf16 plan (what torch.autocast selects, reference train.py:431-435).  At random init with a tiny batch the
+    reference's OWN mixed-precision path (torch CPU autocast bf16) only reaches cosine ~0.7 against its fp32
+    gradients for the early encoder layers, so the bar is relative: our bf16 gradients must agree with the fp32
+    oracle at least as well as the autocast oracle does (minus 0.05), the loss within 1 %, logits within 1.5x of
+    the autocast oracle's own deviation."""
     O, _, _ = pair
-    O.set_seed(42); ref = O.build_model()
-    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
     x, y = O.synthetic_batch(4, 64, seed=1234)
-    ref.train(); model.train()
-    lo = ref(x)
-    loss_o = O.total_loss(lo, y)
-    loss_o.backward()
+
+    def run_oracle(autocast):
+        O.set_seed(42)
+        m = O.build_model()
+        m.train()
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            lo = m(x)
+            loss = O.total_loss(lo.float(), y)
+        loss.backward()
+        return lo.detach().float(), loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    l32, loss32, g32 = run_oracle(False)
+    l16, loss16, g16 = run_oracle(True)
+    O.set_seed(42)
+    model = vk.Unet(encoder_weights=None).to(dev())
+    model.train()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         lg = model(x.to(dev()))
         loss_g = torch.nn.BCEWithLogitsLoss()(lg, y.to(dev())) + vk.DiceLoss(mode="binary")(lg, y.to(dev()))
     loss_g.backward()
     torch.cuda.synchronize()
     assert lg.dtype == torch.float32
-    assert loss_g.item() == pytest.approx(loss_o.item(), rel=2e-2)
-    assert (lg.detach().cpu() - lo.detach()).abs().max().item() <= 0.15 * lo.abs().max().item()
-    named_o = dict(ref.named_parameters())
+    assert loss_g.item() == pytest.approx(loss32, rel=1e-2)
+    ours = (lg.detach().cpu() - l32).abs().mean().item()
+    theirs = (l16 - l32).abs().mean().item()
+    assert ours <= 1.5 * theirs + 1e-3, (ours, theirs)
+
+    def cos(a, b):
+        a, b = a.flatten().double(), b.flatten().double()
+        return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+
     for k, p in model.named_parameters():
         if p.numel() < 4096:
             continue
-        a, b = p.grad.cpu().flatten().double(), named_o[k].grad.flatten().double()
-        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
-        assert cos > 0.98, f"{k}: cosine {cos}"
+        c_ours, c_ref = cos(p.grad.cpu(), g32[k]), cos(g16[k], g32[k])
+        assert c_ours >= c_ref - 0.05, f"{k}: cosine {c_ours} vs autocast oracle {c_ref}"
 
 
 def test_state_dict_roundtrip_with_oracle(pair, tmp_path):

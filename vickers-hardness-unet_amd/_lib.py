@@ -48,6 +48,8 @@ SIGNATURES = {
     "vk_version": (ci, []),
     "vk_last_error_string": (C.c_char_p, []),
     "vk_has_gfx950_code": (ci, []),
+    "vk_prof_enable": (ci, [ci]),
+    "vk_prof_collect": (ci, [C.c_char_p, sz]),
     "vk_conv_fwd": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp, vp]),
     "vk_stem_fwd": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     "vk_conv_wgrad": (ci, [P(vk_conv_desc), vp, vp, vp]),
@@ -147,3 +149,14 @@ def ptr(t) -> int:
 def current_stream() -> int:
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def prof_collect():
+    """Aggregate per-kernel-family timings recorded since vk_prof_enable(1): {tag: dict(n, ms, flops, bytes)}."""
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().vk_prof_collect(buf, len(buf))
+    out = {}
+    for line in buf.raw[:max(n, 0)].decode().splitlines():
+        tag, cnt, ms, fl, by = line.split()
+        out[tag] = dict(n=int(cnt), ms=float(ms), flops=float(fl), bytes=float(by))
+    return out

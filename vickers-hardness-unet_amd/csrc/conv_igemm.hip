@@ -14,6 +14,8 @@
 //   transposed through LDS once and stored as full 16-byte NHWC vectors; the same pass produces the
 //   per-channel sum / sum-of-squares partials for train-mode BatchNorm (fp64 atomics, 2 per channel
 //   per workgroup).
+#include <string>
+
 #include "vk_common.h"
 
 namespace vk {
@@ -417,7 +419,19 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, MODE>), grid, dim3(256), Cfg::SMEM, st, p);
+  {
+    static const std::string tag = std::string(MODE == 2 ? "stem_" : "igemm_") + (sizeof(T) == 4 ? "f32" : "16b") + "_bn" + std::to_string(BN) +
+                                   (MODE == 1 ? "_c16" : "");
+    static const std::string tag_t = tag + "_dgrad";
+    // algorithmic work: real conv MACs (the stride-2 transposed gather executes stride^2 x more) and one read of the
+    // input + weights, one write of the output
+    const double macs = (double)p.M * p.K * (MODE == 2 ? 147.0 : (double)p.RSC) / (p.transposed ? (double)(1 << (2 * p.slog)) : 1.0);
+    const double eb = sizeof(T);
+    const double in_px = p.transposed ? (double)p.N * p.H * p.W : (double)p.N * p.H * p.W;
+    const double bytes = (in_px * (MODE == 2 ? 3 : p.C) + (double)p.M * p.K + (double)p.K * (MODE == 2 ? 147.0 : (double)p.RSC)) * eb;
+    vkh::ProfScope ps((p.transposed ? tag_t : tag).c_str(), st, 2.0 * macs, bytes);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, MODE>), grid, dim3(256), Cfg::SMEM, st, p);
+  }
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }

@@ -11,6 +11,8 @@
 // Split-K over pixel ranges (grid.z) with fp32 atomics into the flat gradient buffer.
 // Two wave layouts: big tiles split the output tile over the 4 waves; small-channel layers
 // (K or C <= 32: decoder blocks 3/4, stem) give every wave the whole tile on its own 32-pixel slice.
+#include <string>
+
 #include "vk_common.h"
 
 namespace vk {
@@ -294,7 +296,16 @@ static int launch_w(WgradParams p, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW, WSPLIT>), grid, dim3(256), Cfg::SMEM, st, p);
+  {
+    static const std::string tag_c = std::string("wgrad_") + (sizeof(T) == 4 ? "f32" : "16b") + "_" + std::to_string(BMW) + "x" + std::to_string(BNW);
+    static const std::string tag_s = std::string("wgrad_stem_") + (sizeof(T) == 4 ? "f32" : "16b");
+    const std::string& tag = p.stem ? tag_s : tag_c;
+    const double rsc = p.stem ? 147.0 : (double)p.RS * p.C;
+    const double eb = sizeof(T);
+    const double bytes = ((double)p.N * p.H * p.W * (p.stem ? 3 : p.C) + (double)p.M * p.K) * eb + (double)p.K * rsc * 4.0;
+    vkh::ProfScope ps(tag.c_str(), st, 2.0 * (double)p.M * p.K * rsc, bytes);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW, WSPLIT>), grid, dim3(256), Cfg::SMEM, st, p);
+  }
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }

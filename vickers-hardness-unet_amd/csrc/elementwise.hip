@@ -582,6 +582,7 @@ using namespace vk;
 extern "C" int vk_input_transform(vk_dtype dtype, int N, int H, int W, const float* x, void* x4, void* stream) {
   VK_CHECK_ARG(x && x4 && N > 0 && H > 0 && W > 0, "vk_input_transform: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("input_transform", st, 0.0, (double)N * H * W * (12.0 + 4.0 * (dtype == VK_F32 ? 4.0 : 2.0)));
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_input_transform<T>, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, st, N, H, W, x, (T*)x4));
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
@@ -592,6 +593,7 @@ extern "C" int vk_bn_finalize(int C, int train, const double* stats, double coun
                               float* save_mean, float* save_invstd, void* stream) {
   VK_CHECK_ARG(C > 0 && gamma && beta && scale && shift, "vk_bn_finalize: null argument");
   VK_CHECK_ARG(train ? (stats != nullptr && count > 0) : (running_mean && running_var), "vk_bn_finalize: missing statistics");
+  vkh::ProfScope ps_("bn_finalize", (hipStream_t)stream, 0.0, (double)C * 40.0);
   hipLaunchKernelGGL(k_bn_finalize, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, train, stats, count, gamma, beta,
                      running_mean, running_var, eps, momentum, scale, shift, save_mean, save_invstd);
   VK_CHECK_HIP(hipGetLastError());
@@ -603,6 +605,7 @@ extern "C" int vk_bn_relu_maxpool(vk_dtype dtype, int N, int H, int W, int C, co
   VK_CHECK_ARG(z && scale && shift && pooled && argmax, "vk_bn_relu_maxpool: null argument");
   VK_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "vk_bn_relu_maxpool: H, W even and C %% 8 == 0 required");
   hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("bn_relu_maxpool", st, 0.0, (double)N * H * W * C * (dtype == VK_F32 ? 4.0 : 2.0) * 1.25 + (double)N * H * W * C / 4.0);
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_relu_maxpool<T>, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * (C / ElemTraits<T>::kVec))),
                                        dim3(256), 0, st, N, H, W, C, (const T*)z, scale, shift, (T*)pooled, argmax));
   VK_CHECK_HIP(hipGetLastError());
@@ -613,6 +616,7 @@ extern "C" int vk_maxpool_bwd(vk_dtype dtype, int N, int H, int W, int C, const 
                               void* stream) {
   VK_CHECK_ARG(dpool && argmax && dy && C % 8 == 0, "vk_maxpool_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("maxpool_bwd", st, 0.0, (double)N * H * W * C * (dtype == VK_F32 ? 4.0 : 2.0) * 2.25 + (double)N * H * W * C / 4.0);
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3(grid_for((size_t)N * H * W * (C / ElemTraits<T>::kVec))), dim3(256), 0, st,
                                        N, H, W, C, (const T*)dpool, argmax, (T*)dy));
   VK_CHECK_HIP(hipGetLastError());
@@ -623,6 +627,7 @@ extern "C" int vk_bn_add_relu(vk_dtype dtype, size_t pixels, int C, const void* 
                               const void* res, const float* rscale, const float* rshift, void* out, void* stream) {
   VK_CHECK_ARG(z && scale && shift && res && out && C % 8 == 0, "vk_bn_add_relu: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("bn_add_relu", st, 0.0, (double)pixels * C * (dtype == VK_F32 ? 4.0 : 2.0) * 3.0);
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_add_relu<T>, dim3(grid_for(pixels * (C / ElemTraits<T>::kVec))), dim3(256), 0, st, pixels, C,
                                        (const T*)z, scale, shift, (const T*)res, rscale, rshift, (T*)out));
   VK_CHECK_HIP(hipGetLastError());
@@ -651,6 +656,7 @@ extern "C" int vk_bn_bwd_reduce(vk_dtype dtype, size_t pixels, int C, const void
   VK_CHECK_ARG(mask_mode != 2 || mask_src, "vk_bn_bwd_reduce: mask_mode 2 needs mask_src");
   VK_CHECK_ARG(C % 8 == 0 && C <= 512, "vk_bn_bwd_reduce: C=%d unsupported", C);
   hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("bn_bwd_reduce", st, 0.0, (double)pixels * C * (dtype == VK_F32 ? 4.0 : 2.0) * (mask_mode == 2 ? 3.0 : 2.0));
   DISPATCH_T(dtype, launch_bn_bwd_reduce<T>(pixels, C, dy, z, mask_mode, scale, shift, mask_src, sums, st));
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
@@ -659,6 +665,7 @@ extern "C" int vk_bn_bwd_reduce(vk_dtype dtype, size_t pixels, int C, const void
 extern "C" int vk_bn_bwd_coeffs(int C, const double* sums, double count, const float* gamma, const float* save_mean,
                                 const float* save_invstd, float* dgamma, float* dbeta, float* coef_abc, void* stream) {
   VK_CHECK_ARG(sums && gamma && save_mean && save_invstd && dgamma && dbeta && coef_abc, "vk_bn_bwd_coeffs: null argument");
+  vkh::ProfScope ps_("bn_bwd_coeffs", (hipStream_t)stream, 0.0, (double)C * 48.0);
   hipLaunchKernelGGL(k_bn_bwd_coeffs, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, sums, count, gamma, save_mean,
                      save_invstd, dgamma, dbeta, coef_abc);
   VK_CHECK_HIP(hipGetLastError());
@@ -684,6 +691,7 @@ extern "C" int vk_bn_bwd_apply(vk_dtype dtype, size_t pixels, int C, const void*
   VK_CHECK_ARG(mask_mode != 1 || (scale && shift), "vk_bn_bwd_apply: mask_mode 1 needs scale/shift");
   VK_CHECK_ARG(mask_mode != 2 || mask_src, "vk_bn_bwd_apply: mask_mode 2 needs mask_src");
   hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("bn_bwd_apply", st, 0.0, (double)pixels * C * (dtype == VK_F32 ? 4.0 : 2.0) * ((mask_mode == 2 ? 4.0 : 3.0) + (g_out ? (g_accumulate ? 2.0 : 1.0) : 0.0)));
   DISPATCH_T(dtype, launch_bn_bwd_apply<T>(pixels, C, dy, z, mask_mode, scale, shift, mask_src, coef_abc, dz, g_out, g_accumulate, st));
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
@@ -693,6 +701,7 @@ extern "C" int vk_upsample2x_bwd(vk_dtype dtype, int N, int H, int W, int C, con
                                  void* stream) {
   VK_CHECK_ARG(d_up && d_low && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "vk_upsample2x_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("upsample2x_bwd", st, 0.0, (double)N * H * W * C * (dtype == VK_F32 ? 4.0 : 2.0) * 1.25);
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_upsample2x_bwd<T>, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * (C / ElemTraits<T>::kVec))),
                                        dim3(256), 0, st, N, H, W, C, (const T*)d_up, (T*)d_low, accumulate));
   VK_CHECK_HIP(hipGetLastError());
@@ -704,6 +713,7 @@ extern "C" int vk_head_fwd(vk_dtype dtype, int N, int H, int W, const vk_src* sr
   VK_CHECK_ARG(src && src->ptr && w9x16 && bias && logits, "vk_head_fwd: null argument");
   VK_CHECK_ARG(src->C == 16 && !src->up, "vk_head_fwd: head input must have 16 channels, no upsample");
   hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("head_fwd", st, 2.0 * 144.0 * N * H * W, (double)N * H * W * (16.0 * (dtype == VK_F32 ? 4.0 : 2.0) + 4.0));
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_fwd<T>, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, st, N, H, W, (const T*)src->ptr,
                                        src->scale, src->shift, src->relu, w9x16, bias, logits));
   VK_CHECK_HIP(hipGetLastError());
@@ -715,6 +725,7 @@ extern "C" int vk_head_bwd(vk_dtype dtype, int N, int H, int W, const vk_src* sr
   VK_CHECK_ARG(src && src->ptr && w9x16 && dlogits && dy && dw9x16 && dbias, "vk_head_bwd: null argument");
   VK_CHECK_ARG(src->C == 16 && !src->up, "vk_head_bwd: head input must have 16 channels, no upsample");
   hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("head_bwd", st, 4.0 * 144.0 * N * H * W, (double)N * H * W * (32.0 * (dtype == VK_F32 ? 4.0 : 2.0) + 4.0));
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_bwd<T>, dim3(grid_for((size_t)N * H * W, 256, 1024)), dim3(256), 0, st, N, H, W,
                                        (const T*)src->ptr, src->scale, src->shift, src->relu, w9x16, dlogits, (T*)dy, dw9x16, dbias));
   VK_CHECK_HIP(hipGetLastError());
@@ -725,6 +736,7 @@ extern "C" int vk_bce_dice_loss(size_t count, const float* logits, const float* 
                                 float* dlogits, float grad_scale, float w_bce, float w_dice, void* stream) {
   VK_CHECK_ARG(count > 0 && logits && target && sums && loss_out, "vk_bce_dice_loss: null argument");
   hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("bce_dice_loss", st, 0.0, (double)count * (dlogits ? 20.0 : 8.0));
   VK_CHECK_HIP(hipMemsetAsync(sums, 0, 8 * sizeof(double), st));
   hipLaunchKernelGGL(k_loss_reduce, dim3(grid_for(count, 256, 1024)), dim3(256), 0, st, count, logits, target, sums);
   hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, (double)count, sums, loss_out, w_bce, w_dice);
@@ -742,6 +754,7 @@ extern "C" int vk_adamw_step(size_t n, float* param, const float* grad, float* e
   const float step_size = (float)((double)lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
   hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("adamw", st, 0.0, (double)n * 28.0);
   dim3 grid(grid_for(n)), block(256);
   if (!lowp_copy || lowp_dtype == VK_F32) {
     hipLaunchKernelGGL(k_adamw<float>, grid, block, 0, st, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,

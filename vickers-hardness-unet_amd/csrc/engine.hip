@@ -24,7 +24,68 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- event profiler -----------------------------------------------------------------------------
+struct ProfRec {
+  const char* tag;
+  hipEvent_t a, b;
+  double flops, bytes;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+
+static hipEvent_t prof_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+ProfScope::ProfScope(const char* tag, hipStream_t stream, double flops, double bytes) : idx(-1), st(stream) {
+  if (!g_prof_on || g_recs.size() >= 200000) return;
+  ProfRec r{tag, prof_event(), prof_event(), flops, bytes};
+  (void)hipEventRecord(r.a, st);
+  idx = (int)g_recs.size();
+  g_recs.push_back(r);
+}
+ProfScope::~ProfScope() {
+  if (idx >= 0) (void)hipEventRecord(g_recs[idx].b, st);
+}
 }  // namespace vkh
+
+extern "C" int vk_prof_enable(int on) {
+  vkh::g_prof_on = on != 0;
+  return VK_OK;
+}
+
+extern "C" int vk_prof_collect(char* buf, size_t buflen) {
+  using namespace vkh;
+  struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::map<std::string, Agg> agg;
+  for (ProfRec& r : g_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      Agg& a = agg[r.tag];
+      a.n += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    }
+    g_pool.push_back(r.a);
+    g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  size_t off = 0;
+  for (auto& kv : agg) {
+    int w = snprintf(buf + off, off < buflen ? buflen - off : 0, "%s %ld %.6f %.6e %.6e\n", kv.first.c_str(), kv.second.n,
+                     kv.second.ms, kv.second.flops, kv.second.bytes);
+    if (w < 0 || off + (size_t)w >= buflen) break;
+    off += (size_t)w;
+  }
+  return (int)off;
+}
 
 extern "C" int vk_version(void) { return VK_ABI_VERSION; }
 extern "C" const char* vk_last_error_string(void) { return vkh::g_err; }

@@ -184,6 +184,15 @@ inline vk::FastDiv make_fastdiv(uint32_t d) {
   return f;
 }
 void set_error(const char* fmt, ...);
+
+// Optional per-launch timing with HIP events on the launch stream (vk_prof_enable / vk_prof_collect).
+// tag: kernel family; flops / bytes: ALGORITHMIC work of this launch (DESIGN.md "roofline accounting").
+struct ProfScope {
+  int idx;
+  hipStream_t st;
+  ProfScope(const char* tag, hipStream_t stream, double flops, double bytes);
+  ~ProfScope();
+};
 }  // namespace vkh
 
 #define VK_CHECK_ARG(cond, ...)                \

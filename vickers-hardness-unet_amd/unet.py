@@ -339,7 +339,7 @@ class Unet(nn.Module):
         self._check_input(x)
         N, _, S, _ = x.shape
         if torch.is_autocast_enabled():
-            dtype = torch.get_autocast_gpu_dtype()
+            dtype = torch.get_autocast_dtype('cuda')
         else:
             dtype = self.compute_dtype
         need_grad = self.training and torch.is_grad_enabled()
