@@ -1,0 +1,406 @@
+// 3x3 stride-1 pad-1 convolution with an LDS-staged input halo tile ("LDS-staged 3x3 input/weight tiles"
+// of the north star).  Covers 27 encoder convs, all 10 decoder convs and the data-gradients of all of
+// them (a 3x3 s1 dgrad is the same conv with flipped taps and [C][RS][K] weights) — >85 % of the conv
+// FLOPs of the U-Net (reference train.py:436 forward, :443/:448 backward).
+//
+// Per workgroup: a TH x 16 pixel tile of one image x BN output channels.
+//   * per 64-byte channel chunk (32 x 16-bit or 16 x fp32 channels) the (TH+2) x 18 halo is staged ONCE
+//     (BatchNorm scale/shift + ReLU, nearest-x2 upsample and channel concat applied on the way) and feeds
+//     all 9 taps: 9x less gather traffic / prologue VALU / LDS writes than tap-by-tap implicit GEMM.
+//   * weights stream through LDS one filter row (3 taps) at a time, double buffered; the next chunk's
+//     halo and the next row's weights are prefetched into registers underneath the MFMAs; one barrier per
+//     filter row (48-96 MFMAs per wave between barriers).
+//   * LDS image: 64-byte rows, 16-byte chunk j of row r stored at j ^ (((r >> 2) & 1) << 1): conflict-free
+//     ds_read_b128 for 16 consecutive rows at ANY row offset (tap shifts), no padding.
+//   * 16x16 MFMA tiles, "swapped" orientation, epilogue through LDS with BN partial sums — as conv_igemm.
+#include <string>
+
+#include "vk_common.h"
+
+namespace vk {
+
+struct HaloSrc {
+  const void* ptr;
+  const float* scale;
+  const float* shift;
+  int C, up, relu;
+  uint32_t bytes;
+};
+
+struct HaloParams {
+  HaloSrc s0, s1;
+  const void* w;
+  uint32_t w_bytes;
+  void* y0;
+  void* y1;
+  int ld0, ld1, split;
+  double* stats;
+  int N, H, W, K, C, flip, accumulate;
+  int tiles_x, tiles_y, nchunks;
+};
+
+template <typename T, int TH, int BN, int WGM, int WGN>
+struct HaloCfg {
+  using Tr = ElemTraits<T>;
+  static constexpr int EB = Tr::kBytes;
+  static constexpr int VE = Tr::kVec;
+  static constexpr int CK = 64 / EB;                 // channels per chunk
+  static constexpr int HW_ = 18, HH = TH + 2, HPIX = HH * HW_;
+  static constexpr int A_BYTES = HPIX * 64;
+  static constexpr int B_BYTES = 3 * BN * 64;
+  static constexpr int NPV = (HPIX * 4 + 255) / 256;   // halo vectors per thread
+  static constexpr int NBV = (3 * BN * 4 + 255) / 256; // weight vectors per thread per filter row
+  static constexpr int BM = TH * 16;
+  static constexpr int WR = TH / WGM;                  // tile rows per wave (= MFMA pixel tiles)
+  static constexpr int WCH = BN / WGN;
+  static constexpr int TP = WR, TC = WCH / 16;
+  static constexpr int ESB = BN * EB + 16;
+  static constexpr int EVPR = BN / VE;
+  static constexpr int ERPP = 256 / EVPR;
+  static constexpr int EPASS = BM / ERPP;
+  static constexpr int RED_OFF = BM * ESB;
+  static constexpr int MAIN = 2 * A_BYTES + 2 * B_BYTES;
+  static constexpr int EPI = RED_OFF + 4 * BN * 2 * 4;
+  static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
+  static_assert(WGM * WGN == 4 && TH % WGM == 0 && BN % (16 * WGN) == 0, "wave layout");
+  static_assert(EPASS >= 1, "epilogue mapping");
+};
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
+
+template <typename T, int TH, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
+  using Cfg = HaloCfg<T, TH, BN, WGM, WGN>;
+  constexpr int EB = Cfg::EB, VE = Cfg::VE, CK = Cfg::CK, HPIX = Cfg::HPIX, NPV = Cfg::NPV, NBV = Cfg::NBV;
+  constexpr int TP = Cfg::TP, TC = Cfg::TC;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Abuf = smem;
+  char* const Bbuf = smem + 2 * Cfg::A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // block -> (image, tile y, tile x), channel tile
+  int bt = blockIdx.x;
+  const int tx = bt % p.tiles_x;
+  bt /= p.tiles_x;
+  const int ty = bt % p.tiles_y;
+  const int n = bt / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const int n0 = blockIdx.y * BN;
+
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.s0.ptr, p.s0.bytes);
+  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.s1.ptr ? p.s1.ptr : p.s0.ptr, p.s1.ptr ? p.s1.bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
+
+  // ---- per-thread halo vectors: pixel offsets in both source geometries
+  const int hv = tid & 3;                       // 16-byte vector inside the 64-byte pixel chunk (fixed per thread)
+  int h_full[NPV], h_half[NPV];                 // pixel index in a full-res / half-res (upsampled) source, -1 = outside
+  const int Hh = p.H >> 1, Wh = p.W >> 1;
+#pragma unroll
+  for (int i = 0; i < NPV; ++i) {
+    const int hp = (tid >> 2) + i * 64;
+    const int hy = hp / 18, hx = hp - hy * 18;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = hp < HPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    h_full[i] = ok ? (n * p.H + y) * p.W + x : -1;
+    h_half[i] = ok ? (n * Hh + (y >> 1)) * Wh + (x >> 1) : -1;
+  }
+
+  u32x4_t areg[NPV], breg[NBV];
+  float sc[VE], sh[VE];
+  bool aff = false, relu = false;
+
+  auto load_halo = [&](int cc) {
+    const int c = cc * CK;
+    const bool first = c < p.s0.C;
+    const HaloSrc& sd = first ? p.s0 : p.s1;
+    const int cl = (first ? c : c - p.s0.C) + hv * VE;
+    aff = sd.scale != nullptr;
+    relu = sd.relu != 0;
+    if (aff) {
+#pragma unroll
+      for (int j = 0; j < VE; j += 4) {
+        const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(sd.scale + cl + j);
+        const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(sd.shift + cl + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[j + e] = s4[e]; sh[j + e] = h4[e]; }
+      }
+    }
+    const bool up = sd.up != 0;
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int pix = up ? h_half[i] : h_full[i];
+      const uint32_t off = (uint32_t)(pix * sd.C + cl) * (uint32_t)EB;
+      if (first) areg[i] = buf_load16(rs0, pix >= 0 ? off : kOOB);
+      else areg[i] = buf_load16(rs1, pix >= 0 ? off : kOOB);
+    }
+  };
+
+  auto store_halo = [&](int buf) {
+    char* A = Abuf + buf * Cfg::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int hp = (tid >> 2) + i * 64;
+      if (hp >= HPIX) continue;
+      u32x4_t v = areg[i];
+      if (aff) {
+        float f[VE];
+        Vec16<T>::unpack(v, f);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+          f[j] = fmaf(f[j], sc[j], sh[j]);
+          if (relu) f[j] = fmaxf(f[j], 0.f);
+        }
+        v = Vec16<T>::pack(f);
+        if (h_full[i] < 0) v = u32x4_t{0, 0, 0, 0};     // zero padding is applied after BN+ReLU
+      }
+      *reinterpret_cast<u32x4_t*>(A + hp * 64 + ((hv ^ swz(hp)) << 4)) = v;
+    }
+  };
+
+  // weights of filter row r, chunk cc: rows n0..n0+BN, taps 3r..3r+2
+  auto load_b = [&](int cc, int r) {
+#pragma unroll
+    for (int i = 0; i < NBV; ++i) {
+      const int idx = tid + i * 256;
+      const int v = idx & 3;
+      const int row = (idx >> 2) % BN;
+      const int s = (idx >> 2) / BN;
+      const int nrow = n0 + row;
+      const bool ok = (idx < 3 * BN * 4) && nrow < p.K;
+      const uint32_t off = (uint32_t)((nrow * 9 + r * 3 + s) * p.C + cc * CK + v * VE) * (uint32_t)EB;
+      breg[i] = buf_load16(rsw, ok ? off : kOOB);
+    }
+  };
+  auto store_b = [&](int buf) {
+    char* B = Bbuf + buf * Cfg::B_BYTES;
+#pragma unroll
+    for (int i = 0; i < NBV; ++i) {
+      const int idx = tid + i * 256;
+      if (idx >= 3 * BN * 4) continue;
+      const int v = idx & 3;
+      const int row = (idx >> 2) % BN;
+      const int s = (idx >> 2) / BN;
+      *reinterpret_cast<u32x4_t*>(B + (s * BN + row) * 64 + ((v ^ swz(row)) << 4)) = breg[i];
+    }
+  };
+
+  // ---- accumulators
+  const int wrow0 = (wave / WGN) * Cfg::WR;
+  const int wch0 = (wave % WGN) * Cfg::WCH;
+  f32x4_t acc[TC][TP];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int li = lane & 15, kg = lane >> 4;
+
+  auto compute = [&](int abuf, int bbuf, int r) {
+    const char* A = Abuf + abuf * Cfg::A_BYTES;
+    const char* B = Bbuf + bbuf * Cfg::B_BYTES;
+    const int rr = p.flip ? 2 - r : r;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int ss = p.flip ? 2 - s : s;
+      u32x4_t wf[TC], xf[TP];
+#pragma unroll
+      for (int a = 0; a < TC; ++a) {
+        const int row = wch0 + a * 16 + li;
+        wf[a] = *reinterpret_cast<const u32x4_t*>(B + (s * BN + row) * 64 + ((kg ^ swz(row)) << 4));
+      }
+#pragma unroll
+      for (int b = 0; b < TP; ++b) {
+        const int hp = (wrow0 + b + rr) * 18 + ss + li;
+        xf[b] = *reinterpret_cast<const u32x4_t*>(A + hp * 64 + ((kg ^ swz(hp)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = Mma<T>::run(wf[a], xf[b], acc[a][b]);
+    }
+  };
+
+  // ---- pipeline over (chunk, filter row) stages
+  load_halo(0);
+  load_b(0, 0);
+  store_halo(0);
+  store_b(0);
+  __syncthreads();
+  const int nst = p.nchunks * 3;
+  int cc = 0, r = 0;
+  for (int st = 0; st < nst; ++st) {
+    const bool more = st + 1 < nst;
+    const bool next_chunk = (r == 0) && (cc + 1 < p.nchunks);
+    int ncc = cc, nr = r + 1;
+    if (nr == 3) { nr = 0; ncc = cc + 1; }
+    if (more) load_b(ncc, nr);
+    if (next_chunk) load_halo(cc + 1);
+    compute(cc & 1, st & 1, r);
+    if (more) store_b((st + 1) & 1);
+    if (next_chunk) store_halo((cc + 1) & 1);
+    __syncthreads();
+    cc = ncc;
+    r = nr;
+  }
+
+  // ---- epilogue: accumulators -> LDS [tile pixel][channel] as T -> 16-byte NHWC stores (+ BN partial sums)
+  constexpr int ESB = Cfg::ESB;
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+      const int ch = wch0 + a * 16 + kg * 4;
+      const int px = (wrow0 + b) * 16 + li;
+      char* dst = smem + px * ESB + ch * EB;
+      if (EB == 4) {
+        *reinterpret_cast<f32x4_t*>(dst) = acc[a][b];
+      } else {
+        float f[8] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3], 0.f, 0.f, 0.f, 0.f};
+        const u32x4_t pk = Vec16<T>::pack(f);
+        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pk[0], pk[1]};
+      }
+    }
+  __syncthreads();
+
+  constexpr int EVPR = Cfg::EVPR, ERPP = Cfg::ERPP, EPASS = Cfg::EPASS;
+  const int e_row = tid / EVPR, e_vec = tid % EVPR;
+  const int col0 = n0 + e_vec * VE;
+  const bool col_ok = col0 < p.K;
+  char* yb = (char*)p.y0;
+  int ld = p.ld0, colx = col0;
+  if (p.split > 0 && col0 >= p.split) { yb = (char*)p.y1; ld = p.ld1; colx = col0 - p.split; }
+  float s1[VE], s2[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+  for (int ps = 0; ps < EPASS; ++ps) {
+    const int row = e_row + ps * ERPP;          // tile pixel index
+    const int y = y0 + (row >> 4), x = x0 + (row & 15);
+    if (y < p.H && x < p.W && col_ok) {
+      const size_t m = ((size_t)n * p.H + y) * p.W + x;
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + row * ESB + e_vec * 16);
+      u32x4_t* gp = reinterpret_cast<u32x4_t*>(yb + (m * ld + colx) * EB);
+      float f[VE];
+      Vec16<T>::unpack(v, f);
+      if (p.accumulate) {
+        float o[VE];
+        Vec16<T>::unpack(*gp, o);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) f[j] += o[j];
+        v = Vec16<T>::pack(f);
+        Vec16<T>::unpack(v, f);
+      }
+#pragma unroll
+      for (int j = 0; j < VE; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
+      *gp = v;
+    }
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+#pragma unroll
+      for (int o = EVPR; o < 64; o <<= 1) {
+        s1[j] += __shfl_xor(s1[j], o, 64);
+        s2[j] += __shfl_xor(s2[j], o, 64);
+      }
+    }
+    float* red = reinterpret_cast<float*>(smem + Cfg::RED_OFF);
+    if (lane < EVPR) {
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        red[(wave * BN + lane * VE + j) * 2 + 0] = s1[j];
+        red[(wave * BN + lane * VE + j) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.K) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      atomicAdd(p.stats + n0 + tid, (double)a);
+      atomicAdd(p.stats + p.K + n0 + tid, (double)b);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+template <typename T, int TH, int BN, int WGM, int WGN>
+static int launch_halo(HaloParams p, hipStream_t st) {
+  using Cfg = HaloCfg<T, TH, BN, WGM, WGN>;
+  p.tiles_x = (p.W + 15) / 16;
+  p.tiles_y = (p.H + TH - 1) / TH;
+  dim3 grid((unsigned)(p.N * p.tiles_y * p.tiles_x), (unsigned)((p.K + BN - 1) / BN), 1);
+  static bool attr_done = false;
+  if (!attr_done && Cfg::SMEM > 64 * 1024) {
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TH, BN, WGM, WGN>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+    attr_done = true;
+  }
+  {
+    static const std::string tag_f = std::string("halo_") + (sizeof(T) == 4 ? "f32" : "16b") + "_t" + std::to_string(TH) + "_bn" + std::to_string(BN);
+    static const std::string tag_d = tag_f + "_dgrad";
+    const double macs = (double)p.N * p.H * p.W * p.K * 9.0 * p.C;
+    const double bytes = ((double)p.N * p.H * p.W * (p.C + p.K) + 9.0 * p.K * p.C) * sizeof(T);
+    vkh::ProfScope ps((p.flip ? tag_d : tag_f).c_str(), st, 2.0 * macs, bytes);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, BN, WGM, WGN>), grid, dim3(256), Cfg::SMEM, st, p);
+  }
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+template <typename T>
+static int halo_select(const HaloParams& p, hipStream_t st) {
+  const long tiles8 = (long)p.N * ((p.H + 7) / 8) * ((p.W + 15) / 16);
+  const long tiles16 = (long)p.N * ((p.H + 15) / 16) * ((p.W + 15) / 16);
+  if (p.K >= 128) {
+    if (tiles8 * ((p.K + 127) / 128) >= 512) return launch_halo<T, 8, 128, 2, 2>(p, st);
+    return launch_halo<T, 8, 64, 2, 2>(p, st);
+  }
+  if (p.K >= 64) {
+    if (tiles16 >= 1024) return launch_halo<T, 16, 64, 4, 1>(p, st);
+    return launch_halo<T, 8, 64, 2, 2>(p, st);
+  }
+  if (p.K >= 32) return launch_halo<T, 16, 32, 4, 1>(p, st);
+  return launch_halo<T, 16, 16, 4, 1>(p, st);
+}
+
+// returns VK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the tap-by-tap kernel)
+int conv3x3_halo_try(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate, double* stats,
+                     hipStream_t st) {
+  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->H != d->Ho || d->W != d->Wo) return VK_ERR_UNSUPPORTED;
+  const int eb = d->dtype == VK_F32 ? 4 : 2;
+  const int ck = 64 / eb;
+  const int C = d->src0.C + (d->src1.ptr ? d->src1.C : 0);
+  if (d->src0.C % ck || (d->src1.ptr && d->src1.C % ck) || d->K % 16) return VK_ERR_UNSUPPORTED;
+  if (d->src1.ptr && d->src1.up) return VK_ERR_UNSUPPORTED;
+  if ((size_t)d->N * d->H * d->W * C * eb >= (1ull << 31) || (size_t)d->N * d->H * d->W >= (1ull << 31)) return VK_ERR_UNSUPPORTED;
+  HaloParams p;
+  auto mk = [&](const vk_src& s) {
+    HaloSrc h;
+    h.ptr = s.ptr; h.scale = s.scale; h.shift = s.shift; h.C = s.C; h.up = s.up; h.relu = s.relu;
+    h.bytes = s.ptr ? (uint32_t)((size_t)d->N * (d->H >> s.up) * (d->W >> s.up) * s.C * eb) : 0u;
+    return h;
+  };
+  p.s0 = mk(d->src0);
+  if (d->src1.ptr) p.s1 = mk(d->src1);
+  else p.s1 = HaloSrc{nullptr, nullptr, nullptr, 0, 0, 0, 0u};
+  p.w = w;
+  p.w_bytes = (uint32_t)((size_t)d->K * 9 * C * eb);
+  p.y0 = y; p.y1 = y1; p.split = split_k1;
+  p.ld0 = split_k1 ? split_k1 : d->K;
+  p.ld1 = split_k1 ? d->K - split_k1 : 0;
+  p.stats = stats;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.K = d->K; p.C = C;
+  p.flip = d->transposed;
+  p.accumulate = accumulate;
+  p.nchunks = C / ck;
+  p.tiles_x = p.tiles_y = 0;
+  switch (d->dtype) {
+    case VK_F32: return halo_select<float>(p, st);
+    case VK_BF16: return halo_select<bf16_t>(p, st);
+    case VK_F16: return halo_select<f16_t>(p, st);
+  }
+  return VK_ERR_ARG;
+}
+
+}  // namespace vk

@@ -14,6 +14,8 @@
 //   transposed through LDS once and stored as full 16-byte NHWC vectors; the same pass produces the
 //   per-channel sum / sum-of-squares partials for train-mode BatchNorm (fp64 atomics, 2 per channel
 //   per workgroup).
+#include <stdlib.h>
+
 #include <string>
 
 #include "vk_common.h"
@@ -464,6 +466,14 @@ static int dispatch(vk_dtype dt, const ConvParams& p, int mode, hipStream_t st) 
   return VK_ERR_ARG;
 }
 
+int conv3x3_halo_try(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate, double* stats,
+                     hipStream_t st);
+
+static bool halo_enabled() {
+  static const bool on = getenv("VK_NO_HALO") == nullptr;
+  return on;
+}
+
 int conv_fwd_impl(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate,
                   double* stats, hipStream_t st) {
   VK_CHECK_ARG(d && w && y, "vk_conv_fwd: null argument");
@@ -483,6 +493,11 @@ int conv_fwd_impl(const vk_conv_desc* d, const void* w, void* y, void* y1, int s
   }
   VK_CHECK_ARG(!d->src0.up || (d->H % 2 == 0 && d->W % 2 == 0), "vk_conv_fwd: upsampled source needs even H, W");
   VK_CHECK_ARG(!(d->src1.ptr && d->src1.up), "vk_conv_fwd: only src0 may be upsampled");
+  if (halo_enabled() && (!d->transposed || d->stride == 1)) {
+    // 3x3 stride-1 convolutions (and their data gradients) go to the LDS-staged halo kernel
+    const int rc = conv3x3_halo_try(d, w, y, y1, split_k1, accumulate, stats, st);
+    if (rc != VK_ERR_UNSUPPORTED) return rc;
+  }
   ConvParams p;
   p.s0 = make_src(d->src0, d->N, d->H, d->W, eb);
   if (d->src1.ptr) {

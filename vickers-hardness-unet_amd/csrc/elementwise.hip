@@ -240,7 +240,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(size_t pixels, int C, con
     s2[j] = 0.f;
   }
   if (active) {
-    for (size_t p = (size_t)blockIdx.x * rows + row; p < pixels; p += (size_t)gridDim.x * rows) {
+    // 4 independent row loads in flight per thread (latency-bound otherwise)
+    const size_t stride = (size_t)gridDim.x * rows;
+    size_t p = (size_t)blockIdx.x * rows + row;
+    for (; p + 3 * stride < pixels; p += 4 * stride) {
+      float g[4][VE], zf[4][VE];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) masked_grad<T, MASK>(dy, z, mask_src, (p + u * stride) * C + cv * VE, sc, sh, g[u], zf[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < VE; ++j) { s1[j] += g[u][j]; s2[j] += g[u][j] * zf[u][j]; }
+    }
+    for (; p < pixels; p += stride) {
       float g[VE], zf[VE];
       masked_grad<T, MASK>(dy, z, mask_src, p * C + cv * VE, sc, sh, g, zf);
 #pragma unroll
@@ -639,8 +651,10 @@ static int launch_bn_bwd_reduce(size_t pixels, int C, const void* dy, const void
                                 const float* shift, const void* mask_src, double* sums, hipStream_t st) {
   const int CV = C / ElemTraits<T>::kVec;
   const int rows = 256 / CV;
-  size_t nb = (pixels + rows - 1) / rows;
+  // every block ends with 2*C fp64 atomics, so give each at least 16 row passes
+  size_t nb = (pixels + (size_t)rows * 16 - 1) / ((size_t)rows * 16);
   if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb), block(256);
   if (mask_mode == 0) hipLaunchKernelGGL((k_bn_bwd_reduce<T, 0>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, sums);
   else if (mask_mode == 1) hipLaunchKernelGGL((k_bn_bwd_reduce<T, 1>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, sums);
