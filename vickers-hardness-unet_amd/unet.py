@@ -184,6 +184,7 @@ class Unet(nn.Module):
             else:
                 mod._buffers[leaf] = v
         self._anchor = torch.zeros((), requires_grad=True, device=self._flat["params"].device)
+        self._param_list = [self._leaves[t[0]][0]._parameters[self._leaves[t[0]][1]] for t in self._table if t[1] in (0, 1)]
 
     def _apply(self, fn, recurse=True):
         for k in ("params", "grads", "bufs", "nbt"):
@@ -281,7 +282,9 @@ class Unet(nn.Module):
         self._dirty += 1
 
     def _weights_version(self):
-        return (self._dirty, self._flat["params"]._version)
+        # Parameter.data views carry their own version counters, so sum them (in-place edits by a stock
+        # torch optimizer or load_state_dict bump them); raw-pointer writers call mark_weights_dirty().
+        return (self._dirty, sum(p._version for p in self._param_list))
 
     # ------------------------------------------------------------------ plans
     def plan_for(self, N: int, S: int, dtype: torch.dtype, training: bool) -> _Plan:
