@@ -10,7 +10,7 @@
  *   vk_unet_loss .............................. bce(logits,y)+dice(logits,y) train.py:438, 513 (600-601)
  *   vk_unet_backward .......................... loss.backward()              train.py:443, 448
  *   vk_adamw_step ............................. optimizer.step()/zero_grad   train.py:428, 449 (606)
- *   vk_amp_unscale_check ...................... GradScaler.unscale_/step     train.py:443-445 (610-611)
+ *   vk_amp_check_inf .......................... GradScaler inf check          train.py:443-445 (610-611)
  *   vk_conv_fwd / vk_conv_wgrad / ... ......... the ATen operators the reference dispatches to
  *                                               (conv2d, batch_norm, relu, max_pool2d, interpolate, cat)
  *

@@ -16,7 +16,7 @@ from conftest import GOLDEN, ROOT
 def test_header_symbols_all_exported(vk):
     hdr = (ROOT / "include" / "vk_unet.h").read_text()
     declared = set(re.findall(r"\b(vk_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"vk_unet_param_info", "vk_amp_unscale_check"}      # names used in prose only
+    declared -= {"vk_unet_param_info"}      # names used in prose only
     L = vk.lib()
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
     assert not missing, missing
