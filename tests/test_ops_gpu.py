@@ -250,12 +250,27 @@ WGRAD_CASES = [
     ("dec4_c1", 1, 40, 32, 16, 3, 1, 1),
     ("dec4_c2", 1, 40, 16, 16, 3, 1, 1),
     ("dec3_c1", 1, 24, 128, 32, 3, 1, 1),
+    ("odd", 3, 13, 32, 48, 3, 1, 1),
+    ("l2_body", 2, 20, 128, 128, 3, 1, 1),
 ]
+
+
+@pytest.fixture(params=["tap", "halo"])
+def wgrad_path(request, monkeypatch):
+    """Run every weight-gradient case through both kernels: the tap-by-tap one and (forced onto these small
+    shapes) the LDS-staged halo one; shapes the halo kernel does not cover fall back by themselves."""
+    if request.param == "tap":
+        monkeypatch.setenv("VK_NO_WGRAD_HALO", "1")
+    else:
+        monkeypatch.delenv("VK_NO_WGRAD_HALO", raising=False)
+        monkeypatch.setenv("VK_WH_MINBLOCKS", "1")
+        monkeypatch.setenv("VK_WH_MAXCOMBO", "1000")
+    return request.param
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
-def test_conv_wgrad(case, dtn):
+def test_conv_wgrad(case, dtn, wgrad_path):
     dt = DT[dtn]
     _, N, H, Cc, K, R, stride, pad = case
     Ho = (H + 2 * pad - R) // stride + 1
@@ -279,7 +294,7 @@ def test_conv_wgrad(case, dtn):
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
-def test_conv_wgrad_upsample_concat(dtn):
+def test_conv_wgrad_upsample_concat(dtn, wgrad_path):
     dt = DT[dtn]
     N, H, Cup, Cskip, K = 1, 16, 128, 64, 64
     lo = gen(N, Cup, H // 2, H // 2, seed=51)

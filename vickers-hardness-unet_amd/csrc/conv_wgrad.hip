@@ -339,9 +339,15 @@ static SrcDevW make_srcw(const vk_src& s, int N, int H, int W, int eb) {
   return d;
 }
 
+int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, hipStream_t st);
+
 int conv_wgrad_impl(const vk_conv_desc* d, const void* dz, float* dw, hipStream_t st) {
   VK_CHECK_ARG(d && dz && dw && d->src0.ptr, "vk_conv_wgrad: null argument");
   VK_CHECK_ARG(!d->transposed, "vk_conv_wgrad: descriptor must describe the forward convolution");
+  {
+    const int rc = wgrad_halo_try(d, dz, dw, st);      // 3x3 stride-1 layers with enough pixels per output tile
+    if (rc != VK_ERR_UNSUPPORTED) return rc;
+  }
   const int eb = d->dtype == VK_F32 ? 4 : 2;
   const int C = d->src0.C + (d->src1.ptr ? d->src1.C : 0);
   VK_CHECK_ARG(d->K % 16 == 0 && C % 16 == 0, "vk_conv_wgrad: K=%d, C=%d must be multiples of 16", d->K, C);
