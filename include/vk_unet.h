@@ -35,6 +35,9 @@ extern "C" {
 #endif
 
 #define VK_ABI_VERSION 1
+/* BatchNorm partial sums are spread over this many replicas ([R][2][K] doubles) so that tens of thousands of
+ * workgroups do not serialise on the same 2K addresses; vk_bn_finalize adds the replicas up. */
+#define VK_STATS_REPLICAS 32
 
 typedef enum { VK_F32 = 0, VK_BF16 = 1, VK_F16 = 2 } vk_dtype;
 
@@ -83,7 +86,7 @@ typedef struct {
 /* y = conv(V, w).  w: [K][R][S][C] of `dtype`.  y: [N][Ho][Wo][K] of `dtype`.
  * If K >= split_k1 > 0 the output channels [split_k1, K) go to y1 (leading dim K - split_k1) and
  * [0, split_k1) to y (leading dim split_k1): the two halves of a concat gradient.
- * accumulate: y (+)= result.  stats: optional double[2][K] receiving sum / sum of squares over
+ * accumulate: y (+)= result.  stats: optional double[VK_STATS_REPLICAS][2][K] receiving (spread over the replicas) sum / sum of squares over
  * N*Ho*Wo of the stored (rounded) outputs — train-mode BatchNorm partials (must be zeroed by caller). */
 int vk_conv_fwd(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate,
                 double* stats, void* stream);
@@ -100,7 +103,7 @@ int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const voi
 /* NCHW fp32 [N][3][H][W] -> NHWC4 `dtype` */
 int vk_input_transform(vk_dtype dtype, int N, int H, int W, const float* x, void* x4, void* stream);
 
-/* BatchNorm statistics -> per-channel affine.  train=1: from batch sums (count = N*H*W), updates
+/* BatchNorm statistics -> per-channel affine.  train=1: from batch sums stats[VK_STATS_REPLICAS][2][C] (count = N*H*W), updates
  * running stats (momentum 0.1, unbiased var) and writes mean/invstd for backward.  train=0: from
  * running stats.  scale = gamma*invstd, shift = beta - mean*scale. */
 int vk_bn_finalize(int C, int train, const double* stats, double count, const float* gamma, const float* beta,

@@ -15,6 +15,7 @@ vk = importlib.import_module("vickers-hardness-unet_amd")
 L_ = vk._lib
 
 DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+REPL = 32       # VK_STATS_REPLICAS in include/vk_unet.h
 
 
 def dev():
@@ -111,7 +112,7 @@ def test_conv_fwd(case, dtn):
         v = rnd(torch.relu(v * sc_c.view(1, -1, 1, 1) + sh_c.view(1, -1, 1, 1)), dt)
     ref = F.conv2d(v.double(), rnd(w, dt).double(), stride=stride, padding=pad).float()
     y = torch.full((N, Ho, Ho, K), float("nan"), dtype=dt, device=dev())
-    stats = torch.zeros(2 * K, dtype=torch.float64, device=dev())
+    stats = torch.zeros(REPL * 2 * K, dtype=torch.float64, device=dev())
     d = conv_desc(dt, N, H, H, Ho, Ho, K, R, stride, pad, 0, mk_src(xd, Cc, 0, sc, sh, 1 if affine else 0))
     vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wd.data_ptr(), y.data_ptr(), None, 0, 0, stats.data_ptr(), st()))
     torch.cuda.synchronize()
@@ -120,7 +121,7 @@ def test_conv_fwd(case, dtn):
     err = (got - ref).abs().max().item()
     assert err <= tol(dt, ref), f"max err {err} vs tol {tol(dt, ref)}"
     # BN partial sums are over the STORED (rounded) outputs
-    s = stats.cpu()
+    s = stats.cpu().view(REPL, 2 * K).sum(0)
     yy = from_nhwc(y).double()
     assert torch.allclose(s[:K], yy.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3 * yy.abs().max().item() * yy[:, 0].numel() ** 0.5)
     assert torch.allclose(s[K:], (yy * yy).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
@@ -173,7 +174,7 @@ def test_stem_fwd(dtn):
     wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
     wpd = D(wp.reshape(64, 7, 32).to(dt))
     y = torch.empty((N, S // 2, S // 2, 64), dtype=dt, device=dev())
-    stats = torch.zeros(128, dtype=torch.float64, device=dev())
+    stats = torch.zeros(REPL * 128, dtype=torch.float64, device=dev())
     vk._lib.check(vk.lib().vk_stem_fwd(L_.dtype_code(dt), N, S, S, x4.data_ptr(), wpd.data_ptr(), y.data_ptr(), stats.data_ptr(), st()))
     torch.cuda.synchronize()
     ref = F.conv2d(rnd(x, dt).double(), rnd(w, dt).double(), stride=2, padding=3).float()
@@ -337,7 +338,10 @@ def test_bn_finalize_train_and_eval():
     Cc, cnt = 64, 1000.0
     g = torch.Generator().manual_seed(71)
     data = torch.randn(1000, Cc, generator=g, dtype=torch.float64) * 2 + 0.5
-    stats = D(torch.cat([data.sum(0), (data * data).sum(0)]))
+    one = torch.cat([data.sum(0), (data * data).sum(0)])
+    spread = torch.zeros(REPL, 2 * Cc, dtype=torch.float64)
+    spread[0], spread[5] = one * 0.25, one * 0.75        # partial sums may sit in any replica
+    stats = D(spread.flatten())
     gamma = D(0.5 + torch.rand(Cc, generator=g))
     beta = D(torch.randn(Cc, generator=g))
     rm, rv = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())

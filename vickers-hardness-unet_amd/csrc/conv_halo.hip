@@ -13,6 +13,8 @@
 //   * LDS image: 64-byte rows, 16-byte chunk j of row r stored at j ^ (((r >> 2) & 1) << 1): conflict-free
 //     ds_read_b128 for 16 consecutive rows at ANY row offset (tap shifts), no padding.
 //   * 16x16 MFMA tiles, "swapped" orientation, epilogue through LDS with BN partial sums — as conv_igemm.
+#include <stdlib.h>
+
 #include <string>
 
 #include "vk_common.h"
@@ -317,8 +319,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
       float a = 0.f, b = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
-      atomicAdd(p.stats + n0 + tid, (double)a);
-      atomicAdd(p.stats + p.K + n0 + tid, (double)b);
+      double* sp = p.stats + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * p.K;
+      atomicAdd(sp + n0 + tid, (double)a);
+      atomicAdd(sp + p.K + n0 + tid, (double)b);
     }
   }
 }
@@ -341,7 +344,9 @@ static int launch_halo(HaloParams p, hipStream_t st) {
     static const std::string tag_d = tag_f + "_dgrad";
     const double macs = (double)p.N * p.H * p.W * p.K * 9.0 * p.C;
     const double bytes = ((double)p.N * p.H * p.W * (p.C + p.K) + 9.0 * p.K * p.C) * sizeof(T);
-    vkh::ProfScope ps((p.flip ? tag_d : tag_f).c_str(), st, 2.0 * macs, bytes);
+    const std::string& btag = p.flip ? tag_d : tag_f;
+    const std::string dtag = getenv("VK_PROF_DETAIL") ? btag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) : btag;
+    vkh::ProfScope ps(dtag.c_str(), st, 2.0 * macs, bytes);
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, BN, WGM, WGN>), grid, dim3(256), Cfg::SMEM, st, p);
   }
   VK_CHECK_HIP(hipGetLastError());

@@ -386,8 +386,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       float a = 0.f, b = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
-      atomicAdd(p.stats + n0 + tid, (double)a);
-      atomicAdd(p.stats + p.K + n0 + tid, (double)b);
+      double* sp = p.stats + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * p.K;
+      atomicAdd(sp + n0 + tid, (double)a);
+      atomicAdd(sp + p.K + n0 + tid, (double)b);
     }
   }
 }
@@ -431,7 +432,9 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
     const double eb = sizeof(T);
     const double in_px = p.transposed ? (double)p.N * p.H * p.W : (double)p.N * p.H * p.W;
     const double bytes = (in_px * (MODE == 2 ? 3 : p.C) + (double)p.M * p.K + (double)p.K * (MODE == 2 ? 147.0 : (double)p.RSC)) * eb;
-    vkh::ProfScope ps((p.transposed ? tag_t : tag).c_str(), st, 2.0 * macs, bytes);
+    const std::string& btag = p.transposed ? tag_t : tag;
+    const std::string dtag = getenv("VK_PROF_DETAIL") ? btag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) + "_R" + std::to_string(p.R) : btag;
+    vkh::ProfScope ps(dtag.c_str(), st, 2.0 * macs, bytes);
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, MODE>), grid, dim3(256), Cfg::SMEM, st, p);
   }
   VK_CHECK_HIP(hipGetLastError());

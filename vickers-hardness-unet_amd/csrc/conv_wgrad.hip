@@ -11,6 +11,8 @@
 // Split-K over pixel ranges (grid.z) with fp32 atomics into the flat gradient buffer.
 // Two wave layouts: big tiles split the output tile over the 4 waves; small-channel layers
 // (K or C <= 32: decoder blocks 3/4, stem) give every wave the whole tile on its own 32-pixel slice.
+#include <stdlib.h>
+
 #include <string>
 
 #include "vk_common.h"
@@ -303,7 +305,8 @@ static int launch_w(WgradParams p, hipStream_t st) {
     const double rsc = p.stem ? 147.0 : (double)p.RS * p.C;
     const double eb = sizeof(T);
     const double bytes = ((double)p.N * p.H * p.W * (p.stem ? 3 : p.C) + (double)p.M * p.K) * eb + (double)p.K * rsc * 4.0;
-    vkh::ProfScope ps(tag.c_str(), st, 2.0 * (double)p.M * p.K * rsc, bytes);
+    const std::string dtag = getenv("VK_PROF_DETAIL") ? tag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) + "_R" + std::to_string(p.R) + "_s" + std::to_string(splits) : tag;
+    vkh::ProfScope ps(dtag.c_str(), st, 2.0 * (double)p.M * p.K * rsc, bytes);
     hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW, WSPLIT>), grid, dim3(256), Cfg::SMEM, st, p);
   }
   VK_CHECK_HIP(hipGetLastError());

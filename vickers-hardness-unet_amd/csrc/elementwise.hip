@@ -43,8 +43,13 @@ __global__ void k_bn_finalize(int C, int train, const double* __restrict__ stats
   if (c >= C) return;
   double mean, var;
   if (train) {
-    mean = stats[c] / count;
-    var = stats[C + c] / count - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < VK_STATS_REPLICAS; ++r) {
+      s1 += stats[(size_t)r * 2 * C + c];
+      s2 += stats[(size_t)r * 2 * C + C + c];
+    }
+    mean = s1 / count;
+    var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
     if (running_mean) {
       const double unb = count > 1.0 ? var * count / (count - 1.0) : var;

@@ -27,7 +27,7 @@ void set_error(const char* fmt, ...) {
 
 // ---- event profiler -----------------------------------------------------------------------------
 struct ProfRec {
-  const char* tag;
+  std::string tag;
   hipEvent_t a, b;
   double flops, bytes;
 };
@@ -435,13 +435,13 @@ void layout_workspace(vk_unet* h) {
   // per-BN statistics (one zero region) and float arena
   size_t st = 0, fl = 0;
   for (BnL& b : h->bns) {
-    st += 2 * (size_t)b.C * sizeof(double);
+    st += 2 * (size_t)b.C * sizeof(double) * VK_STATS_REPLICAS;
     b.arena_off = (int64_t)fl;
     fl += 7 * (size_t)b.C;
   }
   h->stats_bytes = st;
   h->off_stats = take(st);
-  h->off_bsums = take(st);
+  h->off_bsums = take(st / VK_STATS_REPLICAS);
   h->farena_floats = fl;
   h->off_farena = take(fl * sizeof(float));
   h->off_wf = (eb == 4) ? 0 : take((size_t)h->n_params * eb);
@@ -485,7 +485,7 @@ void assign_pointers(vk_unet* h) {
   for (BnL& b : h->bns) {
     b.stats = sp;
     b.bsums = bp;
-    sp += 2 * b.C;
+    sp += 2 * b.C * VK_STATS_REPLICAS;
     bp += 2 * b.C;
     float* f = fa + b.arena_off;
     b.scale = f;
@@ -863,7 +863,7 @@ int backward_stage(vk_unet* h, const float* dlogits, int stage, hipStream_t st) 
   const int N = h->cfg.N, S = h->cfg.size;
   switch (stage) {
     case 0: {
-      VK_CHECK_HIP(hipMemsetAsync(h->ws + h->off_bsums, 0, h->stats_bytes, st));
+      VK_CHECK_HIP(hipMemsetAsync(h->ws + h->off_bsums, 0, h->stats_bytes / VK_STATS_REPLICAS, st));
       ConvL& last = h->convs[h->decs[4].conv2];
       vk_src hs = to_src(bn_act(h, last));
       RET_IF(vk_head_bwd(h->cfg.dtype, N, S, S, &hs, h->params + h->head_w_off, dlogits ? dlogits : (const float*)(h->ws + h->off_dlogits), last.g,

@@ -289,7 +289,9 @@ static int launch_wh(WhParams p, hipStream_t st) {
   const int kt = (p.K + KT - 1) / KT, ct = p.C / CT;
   if (kt * ct > wh_max_combo()) return VK_ERR_UNSUPPORTED;      // deep layers: output tile traffic would dominate
   // every workgroup ends with KT*CT*9 fp32 atomics: give it at least ~6 pixel tiles of work
-  int splits = 1536 / (kt * ct);
+  const char* e_blk = getenv("VK_WH_BLOCKS");
+  const int target_blocks = e_blk ? atoi(e_blk) : (WS ? 1024 : 320);
+  int splits = (target_blocks + kt * ct - 1) / (kt * ct);
   if (splits > p.ntiles / 6) splits = p.ntiles / 6;
   if (splits < 1) splits = 1;
   if ((long)splits * kt * ct < wh_min_blocks()) return VK_ERR_UNSUPPORTED;  // too few workgroups to fill the chip
@@ -303,7 +305,8 @@ static int launch_wh(WhParams p, hipStream_t st) {
   {
     static const std::string tag = std::string("wgrad_halo_") + (sizeof(T) == 4 ? "f32" : "16b") + "_" + std::to_string(KT) + "x" + std::to_string(CT);
     const double bytes = (double)p.N * p.H * p.W * (p.C + p.K) * sizeof(T) + 9.0 * p.K * p.C * 4.0;
-    vkh::ProfScope ps(tag.c_str(), st, 2.0 * (double)p.N * p.H * p.W * p.K * 9.0 * p.C, bytes);
+    const std::string dtag = getenv("VK_PROF_DETAIL") ? tag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) + "_s" + std::to_string(splits) : tag;
+    vkh::ProfScope ps(dtag.c_str(), st, 2.0 * (double)p.N * p.H * p.W * p.K * 9.0 * p.C, bytes);
     hipLaunchKernelGGL((wgrad_halo_kernel<T, KT, CT, WS>), grid, dim3(256), Cfg::SMEM, st, p);
   }
   VK_CHECK_HIP(hipGetLastError());
