@@ -96,8 +96,11 @@ int vk_conv_fwd(const vk_conv_desc* d, const void* w, void* y, void* y1, int spl
 int vk_stem_fwd(vk_dtype dtype, int N, int H, int W, const void* x4, const void* wp, void* y, double* stats,
                 void* stream);
 
-/* dw[K][R][S][C] (fp32, += via atomics; caller zeroes) = sum_pixels dz[n][p][q][k] * V[n][p*stride-pad+r][..][c] */
-int vk_conv_wgrad(const vk_conv_desc* d, const void* dz, float* dw, void* stream);
+/* dw[K][R][S][C] (fp32, +=; caller zeroes once per step) = sum_pixels dz[n][p][q][k] * V[n][p*stride-pad+r][..][c].
+ * workspace (optional, VK_WGRAD_WORKSPACE_BYTES is always enough): when given, the 3x3 stride-1 layers write
+ * per-split partial results there and add them up in a fixed order (reproducible); otherwise fp32 atomics. */
+#define VK_WGRAD_WORKSPACE_BYTES (64u << 20)
+int vk_conv_wgrad(const vk_conv_desc* d, const void* dz, float* dw, void* workspace, size_t workspace_bytes, void* stream);
 int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const void* dz, float* dw_krsc3, void* stream);
 
 /* NCHW fp32 [N][3][H][W] -> NHWC4 `dtype` */

@@ -256,7 +256,10 @@ WGRAD_CASES = [
 ]
 
 
-@pytest.fixture(params=["tap", "halo"])
+WS_ = None      # wgrad workspace of the current test (None => atomics epilogue)
+
+
+@pytest.fixture(params=["tap", "halo", "halo_slab"])
 def wgrad_path(request, monkeypatch):
     """Run every weight-gradient case through both kernels: the tap-by-tap one and (forced onto these small
     shapes) the LDS-staged halo one; shapes the halo kernel does not cover fall back by themselves."""
@@ -266,7 +269,10 @@ def wgrad_path(request, monkeypatch):
         monkeypatch.delenv("VK_NO_WGRAD_HALO", raising=False)
         monkeypatch.setenv("VK_WH_MINBLOCKS", "1")
         monkeypatch.setenv("VK_WH_MAXCOMBO", "1000")
-    return request.param
+    global WS_
+    WS_ = torch.empty(64 << 20, dtype=torch.uint8, device=dev()) if request.param == "halo_slab" else None
+    yield request.param
+    WS_ = None
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
@@ -286,7 +292,7 @@ def test_conv_wgrad(case, dtn, wgrad_path):
     xd, dzd = to_nhwc(x, dt), to_nhwc(dz, dt)
     dw = torch.zeros(K, R, R, Cc, dtype=torch.float32, device=dev())
     d = conv_desc(dt, N, H, H, Ho, Ho, K, R, stride, pad, 0, mk_src(xd, Cc, 0, D(sc_c), D(sh_c), 1))
-    vk._lib.check(vk.lib().vk_conv_wgrad(C.byref(d), dzd.data_ptr(), dw.data_ptr(), st()))
+    vk._lib.check(vk.lib().vk_conv_wgrad(C.byref(d), dzd.data_ptr(), dw.data_ptr(), WS_.data_ptr() if WS_ is not None else None, WS_.numel() if WS_ is not None else 0, st()))
     torch.cuda.synchronize()
     got = dw.cpu().permute(0, 3, 1, 2)
     err = (got - ref).abs().max().item()
@@ -308,7 +314,7 @@ def test_conv_wgrad_upsample_concat(dtn, wgrad_path):
     lod, skd, dzd = to_nhwc(lo, dt), to_nhwc(sk, dt), to_nhwc(dz, dt)
     dw = torch.zeros(K, 3, 3, Cup + Cskip, dtype=torch.float32, device=dev())
     d = conv_desc(dt, N, H, H, H, H, K, 3, 1, 1, 0, mk_src(lod, Cup, 1), mk_src(skd, Cskip))
-    vk._lib.check(vk.lib().vk_conv_wgrad(C.byref(d), dzd.data_ptr(), dw.data_ptr(), st()))
+    vk._lib.check(vk.lib().vk_conv_wgrad(C.byref(d), dzd.data_ptr(), dw.data_ptr(), WS_.data_ptr() if WS_ is not None else None, WS_.numel() if WS_ is not None else 0, st()))
     torch.cuda.synchronize()
     err = (dw.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
     assert err <= (1e-4 if dt == torch.float32 else 2e-3) * ref.abs().max().item(), err

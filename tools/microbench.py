@@ -1,0 +1,83 @@
+"""Stand-alone timing of the convolution kernels at the U-Net's layer shapes (N=32, S=512 geometry).
+
+    python tools/microbench.py [--only L3] [--ops fwd,dgrad,wgrad] [--reps 20] [--dtype bf16]
+Prints per (layer, op): microseconds per launch and algorithmic TFLOP/s (fraction of 2.5 PF)."""
+import argparse
+import ctypes as C
+import importlib
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+vk = importlib.import_module("vickers-hardness-unet_amd")
+L_ = vk._lib
+
+# name: (H, [(C, up)], K)
+LAYERS = {
+    "L1": (128, [(64, 0)], 64), "L2": (64, [(128, 0)], 128), "L3": (32, [(256, 0)], 256), "L4": (16, [(512, 0)], 512),
+    "D0c1": (32, [(512, 1), (256, 0)], 256), "D1c1": (64, [(256, 1), (128, 0)], 128), "D2c1": (128, [(128, 1), (64, 0)], 64),
+    "D3c1": (256, [(64, 1), (64, 0)], 32), "D3c2": (256, [(32, 0)], 32), "D4c1": (512, [(32, 1)], 16), "D4c2": (512, [(16, 0)], 16),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--ops", default="fwd,dgrad,wgrad")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--n", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
+    dev = torch.device("cuda:0")
+    lib = vk.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    N = a.n
+    for name, (H, srcs, K) in LAYERS.items():
+        if a.only and name not in a.only.split(","):
+            continue
+        Ctot = sum(c for c, _ in srcs)
+        ts, ss = [], []
+        for c, up in srcs:
+            t = torch.randn(N, H >> up, H >> up, c, device=dev).to(dt)
+            sc = torch.rand(c, device=dev) + 0.5
+            sh = torch.randn(c, device=dev) * 0.1
+            ts.append((t, sc, sh))
+            ss.append(L_.vk_src(t.data_ptr(), c, up, sc.data_ptr(), sh.data_ptr(), 1))
+        s1 = ss[1] if len(ss) > 1 else L_.vk_src(None, 0, 0, None, None, 0)
+        w = (torch.randn(K, 3, 3, Ctot, device=dev) * 0.05).to(dt)
+        wt = (torch.randn(Ctot, 3, 3, K, device=dev) * 0.05).to(dt)
+        y = torch.empty(N, H, H, K, device=dev, dtype=dt)
+        dz = torch.randn(N, H, H, K, device=dev).to(dt)
+        dx = torch.empty(N, H, H, Ctot, device=dev, dtype=dt)
+        dw = torch.zeros(K, 3, 3, Ctot, device=dev)
+        stats = torch.zeros(32 * 2 * K, dtype=torch.float64, device=dev)
+        wsl = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        d_f = L_.vk_conv_desc(L_.dtype_code(dt), N, H, H, H, H, K, 3, 3, 1, 1, 0, ss[0], s1)
+        d_d = L_.vk_conv_desc(L_.dtype_code(dt), N, H, H, H, H, Ctot, 3, 3, 1, 1, 1,
+                              L_.vk_src(dz.data_ptr(), K, 0, None, None, 0), L_.vk_src(None, 0, 0, None, None, 0))
+        flops = 2.0 * N * H * H * K * 9 * Ctot
+        ops = {
+            "fwd": lambda: lib.vk_conv_fwd(C.byref(d_f), w.data_ptr(), y.data_ptr(), None, 0, 0, stats.data_ptr(), st),
+            "dgrad": lambda: lib.vk_conv_fwd(C.byref(d_d), wt.data_ptr(), dx.data_ptr(), None, 0, 0, None, st),
+            "wgrad": lambda: lib.vk_conv_wgrad(C.byref(d_f), dz.data_ptr(), dw.data_ptr(), wsl.data_ptr(), wsl.numel(), st),
+        }
+        for op in a.ops.split(","):
+            f = ops[op]
+            for _ in range(3):
+                L_.check(f())
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / a.reps
+            print(f"{name:5s} {op:6s} H{H:<4d} C{Ctot:<4d} K{K:<4d} {us:9.1f} us  {flops / us / 1e6:8.1f} TF  ({flops / us / 1e6 / 2500 * 100:5.1f} % of MFMA peak)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,4 @@
+mkdir -p gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L > $GRAFT_REPO_ROOT/gpurun_out/counters.txt 2>&1
+echo rc=$?

@@ -52,7 +52,7 @@ SIGNATURES = {
     "vk_prof_collect": (ci, [C.c_char_p, sz]),
     "vk_conv_fwd": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp, vp]),
     "vk_stem_fwd": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp]),
-    "vk_conv_wgrad": (ci, [P(vk_conv_desc), vp, vp, vp]),
+    "vk_conv_wgrad": (ci, [P(vk_conv_desc), vp, vp, vp, sz, vp]),
     "vk_stem_wgrad": (ci, [ci, ci, ci, ci, vp, vp, vp, vp]),
     "vk_input_transform": (ci, [ci, ci, ci, ci, vp, vp, vp]),
     "vk_bn_finalize": (ci, [ci, ci, vp, cd, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),

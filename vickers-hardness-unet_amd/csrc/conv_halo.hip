@@ -48,8 +48,9 @@ struct HaloCfg {
   static constexpr int VE = Tr::kVec;
   static constexpr int CK = 64 / EB;                 // channels per chunk
   static constexpr int HW_ = 18, HH = TH + 2, HPIX = HH * HW_;
-  static constexpr int A_BYTES = HPIX * 64;
-  static constexpr int B_BYTES = 3 * BN * 64;
+  static constexpr int APS = 96;                     // halo pixel stride: 64 B + 32 B pad => conflict-free at any shift, addresses = base + immediate
+  static constexpr int A_BYTES = HPIX * APS;         // single buffer (next chunk's halo waits in registers)
+  static constexpr int B_BYTES = 3 * BN * 64;        // one filter row of weights, XOR-swizzled 64-B rows, double buffered
   static constexpr int NPV = (HPIX * 4 + 255) / 256;   // halo vectors per thread
   static constexpr int NBV = (3 * BN * 4 + 255) / 256; // weight vectors per thread per filter row
   static constexpr int BM = TH * 16;
@@ -61,7 +62,7 @@ struct HaloCfg {
   static constexpr int ERPP = 256 / EVPR;
   static constexpr int EPASS = BM / ERPP;
   static constexpr int RED_OFF = BM * ESB;
-  static constexpr int MAIN = 2 * A_BYTES + 2 * B_BYTES;
+  static constexpr int MAIN = A_BYTES + 2 * B_BYTES;
   static constexpr int EPI = RED_OFF + 4 * BN * 2 * 4;
   static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
   static_assert(WGM * WGN == 4 && TH % WGM == 0 && BN % (16 * WGN) == 0, "wave layout");
@@ -71,14 +72,14 @@ struct HaloCfg {
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 
 template <typename T, int TH, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p) {
   using Cfg = HaloCfg<T, TH, BN, WGM, WGN>;
   constexpr int EB = Cfg::EB, VE = Cfg::VE, CK = Cfg::CK, HPIX = Cfg::HPIX, NPV = Cfg::NPV, NBV = Cfg::NBV;
-  constexpr int TP = Cfg::TP, TC = Cfg::TC;
+  constexpr int TP = Cfg::TP, TC = Cfg::TC, APS = Cfg::APS;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Abuf = smem;
-  char* const Bbuf = smem + 2 * Cfg::A_BYTES;
+  char* const Bbuf = smem + Cfg::A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // block -> (image, tile y, tile x), channel tile
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
   const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.s1.ptr ? p.s1.ptr : p.s0.ptr, p.s1.ptr ? p.s1.bytes : 0u);
   const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
 
-  // ---- per-thread halo vectors: pixel offsets in both source geometries
+  // ---- per-thread staging geometry, computed once (the main loop only adds block-uniform scalars)
   const int hv = tid & 3;                       // 16-byte vector inside the 64-byte pixel chunk (fixed per thread)
   int h_full[NPV], h_half[NPV];                 // pixel index in a full-res / half-res (upsampled) source, -1 = outside
   const int Hh = p.H >> 1, Wh = p.W >> 1;
@@ -107,8 +108,24 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
     h_full[i] = ok ? (n * p.H + y) * p.W + x : -1;
     h_half[i] = ok ? (n * Hh + (y >> 1)) * Wh + (x >> 1) : -1;
   }
+  // weights: element offset of this thread's vectors for filter row 0 / chunk 0; data-gradient mode walks the taps
+  // backwards (tap 8 - t) instead of flipping the halo accesses
+  int b_goff[NBV], b_loff[NBV];
+#pragma unroll
+  for (int i = 0; i < NBV; ++i) {
+    const int idx = tid + i * 256;
+    const int v = idx & 3;
+    const int row = (idx >> 2) % BN;
+    const int s = (idx >> 2) / BN;
+    const int nrow = n0 + row;
+    const bool ok = (idx < 3 * BN * 4) && nrow < p.K;
+    const int tap = p.flip ? 8 - s : s;
+    b_goff[i] = ok ? (nrow * 9 + tap) * p.C + v * VE : -1;
+    b_loff[i] = (s * BN + row) * 64 + ((v ^ swz(row)) << 4);
+  }
+  const int b_rowstep = (p.flip ? -3 : 3) * p.C;   // element step per filter row
 
-  u32x4_t areg[NPV], breg[NBV];
+  u32x4_t areg[NPV], breg0[NBV], breg1[NBV];   // weights are prefetched TWO filter rows ahead (two register sets)
   float sc[VE], sh[VE];
   bool aff = false, relu = false;
 
@@ -138,8 +155,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
     }
   };
 
-  auto store_halo = [&](int buf) {
-    char* A = Abuf + buf * Cfg::A_BYTES;
+  auto store_halo = [&]() {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
       const int hp = (tid >> 2) + i * 64;
@@ -156,38 +172,26 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
         v = Vec16<T>::pack(f);
         if (h_full[i] < 0) v = u32x4_t{0, 0, 0, 0};     // zero padding is applied after BN+ReLU
       }
-      *reinterpret_cast<u32x4_t*>(A + hp * 64 + ((hv ^ swz(hp)) << 4)) = v;
+      *reinterpret_cast<u32x4_t*>(Abuf + hp * APS + hv * 16) = v;
     }
   };
 
-  // weights of filter row r, chunk cc: rows n0..n0+BN, taps 3r..3r+2
-  auto load_b = [&](int cc, int r) {
+  // weights of filter row r, chunk cc: rows n0..n0+BN, three taps
+  auto load_b = [&](u32x4_t (&breg)[NBV], int stage) {
+    const int cc = stage / 3, r = stage - cc * 3;
+    const int uoff = r * b_rowstep + cc * CK;      // block-uniform (taps run 8..0 in data-gradient mode)
 #pragma unroll
-    for (int i = 0; i < NBV; ++i) {
-      const int idx = tid + i * 256;
-      const int v = idx & 3;
-      const int row = (idx >> 2) % BN;
-      const int s = (idx >> 2) / BN;
-      const int nrow = n0 + row;
-      const bool ok = (idx < 3 * BN * 4) && nrow < p.K;
-      const uint32_t off = (uint32_t)((nrow * 9 + r * 3 + s) * p.C + cc * CK + v * VE) * (uint32_t)EB;
-      breg[i] = buf_load16(rsw, ok ? off : kOOB);
-    }
+    for (int i = 0; i < NBV; ++i)
+      breg[i] = buf_load16(rsw, b_goff[i] >= 0 ? (uint32_t)(b_goff[i] + uoff) * (uint32_t)EB : kOOB);
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](const u32x4_t (&breg)[NBV], int buf) {
     char* B = Bbuf + buf * Cfg::B_BYTES;
 #pragma unroll
-    for (int i = 0; i < NBV; ++i) {
-      const int idx = tid + i * 256;
-      if (idx >= 3 * BN * 4) continue;
-      const int v = idx & 3;
-      const int row = (idx >> 2) % BN;
-      const int s = (idx >> 2) / BN;
-      *reinterpret_cast<u32x4_t*>(B + (s * BN + row) * 64 + ((v ^ swz(row)) << 4)) = breg[i];
-    }
+    for (int i = 0; i < NBV; ++i)
+      if (tid + i * 256 < 3 * BN * 4) *reinterpret_cast<u32x4_t*>(B + b_loff[i]) = breg[i];
   };
 
-  // ---- accumulators
+  // ---- accumulators and per-lane fragment bases (fragment reads are base + immediate)
   const int wrow0 = (wave / WGN) * Cfg::WR;
   const int wch0 = (wave % WGN) * Cfg::WCH;
   f32x4_t acc[TC][TP];
@@ -196,25 +200,19 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
 #pragma unroll
     for (int b = 0; b < TP; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int li = lane & 15, kg = lane >> 4;
+  const char* const a_lane = Abuf + (wrow0 * 18 + li) * APS + kg * 16;
+  const int b_lane = (wch0 + li) * 64 + ((kg ^ swz(li)) << 4);       // swz(row) only depends on li: rows step by 16
 
-  auto compute = [&](int abuf, int bbuf, int r) {
-    const char* A = Abuf + abuf * Cfg::A_BYTES;
-    const char* B = Bbuf + bbuf * Cfg::B_BYTES;
-    const int rr = p.flip ? 2 - r : r;
+  auto compute = [&](int bbuf, int r) {
+    const char* A = a_lane + r * (18 * APS);
+    const char* B = Bbuf + bbuf * Cfg::B_BYTES + b_lane;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      const int ss = p.flip ? 2 - s : s;
       u32x4_t wf[TC], xf[TP];
 #pragma unroll
-      for (int a = 0; a < TC; ++a) {
-        const int row = wch0 + a * 16 + li;
-        wf[a] = *reinterpret_cast<const u32x4_t*>(B + (s * BN + row) * 64 + ((kg ^ swz(row)) << 4));
-      }
+      for (int a = 0; a < TC; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(B + (s * BN + a * 16) * 64);
 #pragma unroll
-      for (int b = 0; b < TP; ++b) {
-        const int hp = (wrow0 + b + rr) * 18 + ss + li;
-        xf[b] = *reinterpret_cast<const u32x4_t*>(A + hp * 64 + ((kg ^ swz(hp)) << 4));
-      }
+      for (int b = 0; b < TP; ++b) xf[b] = *reinterpret_cast<const u32x4_t*>(A + (b * 18 + s) * APS);
 #pragma unroll
       for (int a = 0; a < TC; ++a)
 #pragma unroll
@@ -222,27 +220,33 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
     }
   };
 
-  // ---- pipeline over (chunk, filter row) stages
-  load_halo(0);
-  load_b(0, 0);
-  store_halo(0);
-  store_b(0);
-  __syncthreads();
+  // ---- pipeline over (chunk, filter row) stages.  Halo: single LDS buffer, next chunk waits in registers for three
+  // stages.  Weights: two LDS buffers + two register sets, i.e. the global loads of stage s+2 are issued before the
+  // MFMAs of stage s and written to LDS after the MFMAs of stage s+1 (a full stage of slack for the L2/HBM latency).
   const int nst = p.nchunks * 3;
-  int cc = 0, r = 0;
-  for (int st = 0; st < nst; ++st) {
-    const bool more = st + 1 < nst;
-    const bool next_chunk = (r == 0) && (cc + 1 < p.nchunks);
-    int ncc = cc, nr = r + 1;
-    if (nr == 3) { nr = 0; ncc = cc + 1; }
-    if (more) load_b(ncc, nr);
-    if (next_chunk) load_halo(cc + 1);
-    compute(cc & 1, st & 1, r);
-    if (more) store_b((st + 1) & 1);
-    if (next_chunk) store_halo((cc + 1) & 1);
+  load_halo(0);
+  load_b(breg0, 0);
+  store_halo();
+  store_b(breg0, 0);
+  if (nst > 1) load_b(breg1, 1);
+  __syncthreads();
+
+  auto stage = [&](int st, u32x4_t (&ld_regs)[NBV], const u32x4_t (&st_regs)[NBV]) {
+    const int cc = st / 3, r = st - cc * 3;
+    const bool next_chunk = cc + 1 < p.nchunks;
+    if (st + 2 < nst) load_b(ld_regs, st + 2);
+    if (r == 0 && next_chunk) load_halo(cc + 1);
+    compute(st & 1, r);
+    if (r == 2 && next_chunk) {
+      __syncthreads();                                  // every wave is done reading this chunk's halo
+      store_halo();
+    }
+    if (st + 1 < nst) store_b(st_regs, (st + 1) & 1);
     __syncthreads();
-    cc = ncc;
-    r = nr;
+  };
+  for (int st = 0; st < nst; st += 2) {
+    stage(st, breg0, breg1);                            // even stage: reads B[0], stores set 1 -> B[1], loads set 0
+    if (st + 1 < nst) stage(st + 1, breg1, breg0);      // odd stage : reads B[1], stores set 0 -> B[0], loads set 1
   }
 
   // ---- epilogue: accumulators -> LDS [tile pixel][channel] as T -> 16-byte NHWC stores (+ BN partial sums)

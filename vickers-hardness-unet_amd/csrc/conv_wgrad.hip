@@ -342,13 +342,13 @@ static SrcDevW make_srcw(const vk_src& s, int N, int H, int W, int eb) {
   return d;
 }
 
-int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, hipStream_t st);
+int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, void* workspace, size_t workspace_bytes, hipStream_t st);
 
-int conv_wgrad_impl(const vk_conv_desc* d, const void* dz, float* dw, hipStream_t st) {
+int conv_wgrad_impl(const vk_conv_desc* d, const void* dz, float* dw, void* workspace, size_t workspace_bytes, hipStream_t st) {
   VK_CHECK_ARG(d && dz && dw && d->src0.ptr, "vk_conv_wgrad: null argument");
   VK_CHECK_ARG(!d->transposed, "vk_conv_wgrad: descriptor must describe the forward convolution");
   {
-    const int rc = wgrad_halo_try(d, dz, dw, st);      // 3x3 stride-1 layers with enough pixels per output tile
+    const int rc = wgrad_halo_try(d, dz, dw, workspace, workspace_bytes, st);      // 3x3 stride-1 layers with enough pixels per output tile
     if (rc != VK_ERR_UNSUPPORTED) return rc;
   }
   const int eb = d->dtype == VK_F32 ? 4 : 2;
@@ -413,8 +413,8 @@ int stem_wgrad_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void
 
 }  // namespace vk
 
-extern "C" int vk_conv_wgrad(const vk_conv_desc* d, const void* dz, float* dw, void* stream) {
-  return vk::conv_wgrad_impl(d, dz, dw, (hipStream_t)stream);
+extern "C" int vk_conv_wgrad(const vk_conv_desc* d, const void* dz, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
+  return vk::conv_wgrad_impl(d, dz, dw, workspace, workspace_bytes, (hipStream_t)stream);
 }
 extern "C" int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const void* dz, float* dw_krsc3,
                              void* stream) {

@@ -236,7 +236,7 @@ struct vk_unet {
   size_t ws_bytes = 0;
   size_t off_x4 = 0, off_pool = 0, off_argmax = 0, off_gpool = 0, off_dup = 0, off_dlogits = 0, off_loss_sums = 0;
   size_t off_stats = 0, off_bsums = 0, stats_bytes = 0, off_farena = 0, farena_floats = 0, off_wf = 0, off_wd = 0, off_wstem = 0;
-  size_t off_tab_pack = 0, off_tab_bn = 0;
+  size_t off_tab_pack = 0, off_tab_bn = 0, off_wslab = 0;
   std::vector<size_t> off_z, off_g, off_out, off_gout;
   // bound pointers
   float* params = nullptr;
@@ -447,6 +447,7 @@ void layout_workspace(vk_unet* h) {
   h->off_wf = (eb == 4) ? 0 : take((size_t)h->n_params * eb);
   h->off_wd = tr ? take((size_t)h->n_dgrad * eb) : 0;
   h->off_wstem = take(64 * 7 * 32 * eb);
+  h->off_wslab = tr ? take(VK_WGRAD_WORKSPACE_BYTES) : 0;
   h->off_tab_pack = take(h->convs.size() * sizeof(PackEntry));
   h->off_tab_bn = take(h->bns.size() * sizeof(BnEvalEntry));
   h->ws_bytes = off;
@@ -746,7 +747,7 @@ int bn_relu_bwd_inplace(vk_unet* h, ConvL& c, hipStream_t st) {
 
 int conv_wgrad(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, hipStream_t st) {
   vk_conv_desc d = conv_desc(h, c, s0, s1);
-  return vk_conv_wgrad(&d, c.g, h->grads + c.w_off, st);
+  return vk_conv_wgrad(&d, c.g, h->grads + c.w_off, h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, st);
 }
 
 // dx = dgrad(dz of conv c) into y (and y1 for the channel split)

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include <string>
+#include <type_traits>
 
 #include "vk_common.h"
 
@@ -35,35 +36,43 @@ struct WhParams {
   float* dw;
   int N, H, W, K, C;
   int tiles_x, tiles_y, ntiles, splits;
+  int dbg_skip_epilogue;      // timing experiments only (VK_WH_DBG_NOEPI)
+  float* slab;                // [splits][K][9][C] partial results (deterministic two-stage reduce) or nullptr (atomics)
 };
 
-template <typename T, int KT, int CT, bool WS>
+template <typename T, int KT, int CT, bool WS, bool TS = false>
 struct WhCfg {
   using Tr = ElemTraits<T>;
   static constexpr int EB = Tr::kBytes, VE = Tr::kVec;
   static constexpr int TH = 8, PX = 128, HPIX = 10 * 18;
+  static constexpr int NT = TS ? 512 : 256;                    // TS: two wave groups share the staged tiles, taps 0-4 / 5-8
+  static constexpr int NTAP = TS ? 5 : 9;                      // accumulated taps per wave
   static constexpr int ZV = KT / VE, VV = CT / VE;
-  static constexpr int ZPASS = (PX * ZV + 255) / 256, VPASS = (HPIX * VV + 255) / 256;
+  static constexpr int ZPASS = (PX * ZV + NT - 1) / NT, VPASS = (HPIX * VV + NT - 1) / NT;
   static constexpr int zpad(int ch) { return EB == 2 ? (((ch * 2 / 32) % 2 == 0) ? 32 : 0) : ((ch % 32 == 0) ? 64 : 0); }
   static constexpr int ZSB = KT * EB + zpad(KT);
   static constexpr int VSB = CT * EB + zpad(CT);
   static constexpr int STAGE = PX * ZSB + HPIX * VSB;
   static constexpr int WK = WS ? KT : KT / 2, WC = WS ? CT : CT / 2;
   static constexpr int TK = WK / 16, TCc = WC / 16;
-  static constexpr int RED = WS ? KT * CT * 9 * 4 : 0;
-  static constexpr int SMEM = (2 * STAGE > RED) ? 2 * STAGE : RED;
-  static_assert(TK >= 1 && TCc >= 1 && TK * TCc * 9 <= 36, "accumulator budget");
+  static constexpr int RED = KT * CT * 9 * 4;      // fp32 [KT][9][CT] output tile staged for coalesced stores
+  static constexpr int NSTAGE = 2;
+  static constexpr int SMEM = (NSTAGE * STAGE > RED) ? NSTAGE * STAGE : RED;
+  static_assert(TK >= 1 && TCc >= 1 && TK * TCc * NTAP <= 36, "accumulator budget");
+  static_assert(!(TS && WS), "tap split is for the 2x2 wave layout");
 };
 
-template <typename T, int KT, int CT, bool WS>
-__global__ __launch_bounds__(256) void wgrad_halo_kernel(const WhParams p) {
-  using Cfg = WhCfg<T, KT, CT, WS>;
+template <typename T, int KT, int CT, bool WS, bool TS>
+__global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhParams p) {
+  using Cfg = WhCfg<T, KT, CT, WS, TS>;
+  constexpr int NT = Cfg::NT, NTAP = Cfg::NTAP;
   constexpr int EB = Cfg::EB, VE = Cfg::VE, PX = Cfg::PX, HPIX = Cfg::HPIX, ZV = Cfg::ZV, VV = Cfg::VV;
   constexpr int ZPASS = Cfg::ZPASS, VPASS = Cfg::VPASS, ZSB = Cfg::ZSB, VSB = Cfg::VSB, STAGE = Cfg::STAGE;
   constexpr int TK = Cfg::TK, TCc = Cfg::TCc;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 8);   // tap group (TS); wave-uniform by construction
   const int k0 = blockIdx.x * KT;
   const int c0 = blockIdx.y * CT;                 // channel in concat space
   const bool first = c0 < p.s0.C;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WhParams p) {
 
   // this thread's V vectors always cover the same channels -> scale/shift once
   float sc[VE], sh[VE];
-  const int vvec = tid % VV;                       // VV divides 256
+  const int vvec = tid % VV;                       // VV divides NT
 #pragma unroll
   for (int j = 0; j < VE; ++j) {
     sc[j] = affine ? sd.scale[cl0 + vvec * VE + j] : 1.f;
@@ -88,6 +97,27 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WhParams p) {
   u32x4_t zreg[ZPASS], vreg[VPASS];
   uint32_t vmask = 0;
 
+  // ---- per-thread staging geometry relative to the tile origin, computed once
+  int z_rel[ZPASS], z_yx[ZPASS];                 // element offset (py*W + px)*K + k, packed (py << 8 | px), -1 = unused slot
+  int v_rel[VPASS], v_yx[VPASS];                 // element offset in the (possibly half-res) source, packed ((hy) << 8 | hx)
+#pragma unroll
+  for (int i = 0; i < ZPASS; ++i) {
+    const int v = tid + i * NT;
+    const int px = v / ZV, vec = v % ZV;
+    const bool ok = (v < PX * ZV) && (k0 + vec * VE < p.K);
+    z_rel[i] = ((px >> 4) * p.W + (px & 15)) * p.K + k0 + vec * VE;
+    z_yx[i] = ok ? (((px >> 4) << 8) | (px & 15)) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < VPASS; ++i) {
+    const int v = tid + i * NT;
+    const int hp = v / VV, vec = v % VV;
+    const int hy = hp / 18, hx = hp - hy * 18;
+    const bool ok = v < HPIX * VV;
+    v_rel[i] = (((hy - 1) >> up) * Ws + ((hx - 1) >> up)) * sd.C + cl0 + vec * VE;     // tile origins are even
+    v_yx[i] = ok ? ((hy << 8) | hx) : -1;
+  }
+
   auto load_tile = [&](int t) {
     int tt = t;
     const int tx = tt % p.tiles_x;
@@ -95,25 +125,19 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WhParams p) {
     const int ty = tt % p.tiles_y;
     const int n = tt / p.tiles_y;
     const int y0 = ty * 8, x0 = tx * 16;
+    const int zbase = ((n * p.H + y0) * p.W + x0) * p.K;                                // block-uniform
+    const int vbase = ((n * Hs + (y0 >> up)) * Ws + (x0 >> up)) * sd.C;
 #pragma unroll
     for (int i = 0; i < ZPASS; ++i) {
-      const int v = tid + i * 256;
-      const int px = v / ZV, vec = v % ZV;
-      const int y = y0 + (px >> 4), x = x0 + (px & 15);
-      const bool ok = (v < PX * ZV) && y < p.H && x < p.W && (k0 + vec * VE < p.K);
-      const uint32_t off = (uint32_t)(((n * p.H + y) * p.W + x) * p.K + k0 + vec * VE) * (uint32_t)EB;
-      zreg[i] = buf_load16(rsz, ok ? off : kOOB);
+      const bool ok = z_yx[i] >= 0 && y0 + (z_yx[i] >> 8) < p.H && x0 + (z_yx[i] & 255) < p.W;
+      zreg[i] = buf_load16(rsz, ok ? (uint32_t)(zbase + z_rel[i]) * (uint32_t)EB : kOOB);
     }
     vmask = 0;
 #pragma unroll
     for (int i = 0; i < VPASS; ++i) {
-      const int v = tid + i * 256;
-      const int hp = v / VV, vec = v % VV;
-      const int hy = hp / 18, hx = hp - hy * 18;
-      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-      const bool ok = (v < HPIX * VV) && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      const uint32_t off = (uint32_t)(((n * Hs + (y >> up)) * Ws + (x >> up)) * sd.C + cl0 + vec * VE) * (uint32_t)EB;
-      vreg[i] = buf_load16(rsv, ok ? off : kOOB);
+      const int y = y0 - 1 + (v_yx[i] >> 8), x = x0 - 1 + (v_yx[i] & 255);
+      const bool ok = v_yx[i] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      vreg[i] = buf_load16(rsv, ok ? (uint32_t)(vbase + v_rel[i]) * (uint32_t)EB : kOOB);
       vmask |= (ok ? 1u : 0u) << i;
     }
   };
@@ -123,12 +147,12 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WhParams p) {
     char* Vs = Zs + PX * ZSB;
 #pragma unroll
     for (int i = 0; i < ZPASS; ++i) {
-      const int v = tid + i * 256;
+      const int v = tid + i * NT;
       if (v < PX * ZV) *reinterpret_cast<u32x4_t*>(Zs + (v / ZV) * ZSB + (v % ZV) * 16) = zreg[i];
     }
 #pragma unroll
     for (int i = 0; i < VPASS; ++i) {
-      const int v = tid + i * 256;
+      const int v = tid + i * NT;
       u32x4_t x = vreg[i];
       if (affine) {
         float f[VE];
@@ -147,37 +171,45 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WhParams p) {
 
   const int wk0 = WS ? 0 : (wave >> 1) * Cfg::WK;
   const int wc0 = WS ? 0 : (wave & 1) * Cfg::WC;
-  f32x4_t acc[9][TK][TCc];
+  f32x4_t acc[NTAP][TK][TCc];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NTAP; ++t)
 #pragma unroll
     for (int a = 0; a < TK; ++a)
 #pragma unroll
       for (int b = 0; b < TCc; ++b) acc[t][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+  // transposed-read lane geometry: lane j of 16-lane group g supplies pixel 4g + (j>>2), channels 4*(j&3)..+3
+  const int lane_z = (4 * (lane >> 4) + ((lane & 15) >> 2)) * ZSB + (wk0 + 4 * (lane & 3)) * 2;
+  const int lane_v = (4 * (lane >> 4) + ((lane & 15) >> 2)) * VSB + (wc0 + 4 * (lane & 3)) * 2;
 
   // one 32-pixel reduction step = tile rows (2*ks, 2*ks+1)
   auto compute_step = [&](const char* Zs, const char* Vs, int ks) {
     if (EB == 2) {
-      const int g = lane >> 4, j = lane & 15, q = j >> 2, pp = j & 3;
+      const char* const Zl = Zs + lane_z;      // fragment reads are lane base + immediate
+      const char* const Vl = Vs + lane_v;
       u32x4_t zf[TK];
 #pragma unroll
       for (int a = 0; a < TK; ++a) {
-        const char* b0 = Zs + (32 * ks + 4 * g + q) * ZSB + (wk0 + a * 16 + 4 * pp) * 2;
+        const char* b0 = Zl + (32 * ks) * ZSB + (a * 16) * 2;
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0));
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + 16 * ZSB));
         const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
         zf[a] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
       }
+      auto taps16 = [&](auto tap0_c, auto ntap_c) {
+        constexpr int TAP0 = decltype(tap0_c)::value, NTP = decltype(ntap_c)::value;
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int t = 0; t < NTP; ++t) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int tap = TAP0 + t;
+          const int r = tap / 3, s = tap - r * 3;
           u32x4_t vf[TCc];
 #pragma unroll
           for (int b = 0; b < TCc; ++b) {
-            const char* b0 = Vs + ((2 * ks + r) * 18 + 4 * g + q + s) * VSB + (wc0 + b * 16 + 4 * pp) * 2;
+            const char* b0 = Vl + ((2 * ks + r) * 18 + s) * VSB + (b * 16) * 2;
             const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0));
             const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + 18 * VSB));
             const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
@@ -186,8 +218,12 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WhParams p) {
 #pragma unroll
           for (int a = 0; a < TK; ++a)
 #pragma unroll
-            for (int b = 0; b < TCc; ++b) acc[r * 3 + s][a][b] = Mma<T>::run(zf[a], vf[b], acc[r * 3 + s][a][b]);
+            for (int b = 0; b < TCc; ++b) acc[t][a][b] = Mma<T>::run(zf[a], vf[b], acc[t][a][b]);
         }
+      };
+      if (!TS) taps16(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+      else if (half == 0) taps16(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+      else taps16(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
     } else {
       const int i = lane & 15, kg = lane >> 4;
 #pragma unroll
@@ -197,10 +233,12 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WhParams p) {
         float zf[TK];
 #pragma unroll
         for (int a = 0; a < TK; ++a) zf[a] = *reinterpret_cast<const float*>(Zs + px * ZSB + (wk0 + a * 16 + i) * 4);
+        auto taps32 = [&](auto tap0_c, auto ntap_c) {
+          constexpr int TAP0 = decltype(tap0_c)::value, NTP = decltype(ntap_c)::value;
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int s = 0; s < 3; ++s) {
+          for (int t = 0; t < NTP; ++t) {
+            const int tap = TAP0 + t;
+            const int r = tap / 3, s = tap - r * 3;
             float vf[TCc];
 #pragma unroll
             for (int b = 0; b < TCc; ++b)
@@ -209,8 +247,12 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WhParams p) {
             for (int a = 0; a < TK; ++a)
 #pragma unroll
               for (int b = 0; b < TCc; ++b)
-                acc[r * 3 + s][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[a], vf[b], acc[r * 3 + s][a][b], 0, 0, 0);
+                acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[a], vf[b], acc[t][a][b], 0, 0, 0);
           }
+        };
+        if (!TS) taps32(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+        else if (half == 0) taps32(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+        else taps32(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
       }
     }
   };
@@ -239,50 +281,86 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WhParams p) {
   }
 
   // ---- epilogue
+  if (p.dbg_skip_epilogue) {
+    if (acc[0][0][0][0] == 123.456f) p.dw[0] = 1.f;     // keep the accumulators alive
+    return;
+  }
+  // stage the fp32 output tile [k][tap][c] in LDS (WS: the four waves add their partial tiles with LDS atomics),
+  // then write whole 16-byte vectors: plain stores into this split's slab, or fp32 atomics when no slab was given
+  float* red = reinterpret_cast<float*>(smem);
   if (WS) {
-    float* red = reinterpret_cast<float*>(smem);
-    for (int i = tid; i < KT * CT * 9; i += 256) red[i] = 0.f;
+    for (int i = tid; i < KT * CT * 9; i += NT) red[i] = 0.f;
     __syncthreads();
+  }
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
+  for (int t = 0; t < NTAP; ++t) {
+    const int tp = (TS && half) ? 5 + t : t;
+    if (tp >= 9) continue;
 #pragma unroll
-      for (int a = 0; a < TK; ++a)
+    for (int a = 0; a < TK; ++a)
 #pragma unroll
-        for (int b = 0; b < TCc; ++b)
+      for (int b = 0; b < TCc; ++b)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int k = a * 16 + (lane >> 4) * 4 + e, c = b * 16 + (lane & 15);
-            atomicAdd(red + (k * 9 + tp) * CT + c, acc[tp][a][b][e]);
-          }
-    __syncthreads();
-    for (int i = tid; i < KT * CT * 9; i += 256) {
-      const int c = i % CT, kt = i / CT;
-      const int k = kt / 9, tp = kt - k * 9;
-      if (k0 + k < p.K) atomicAdd(p.dw + ((size_t)(k0 + k) * 9 + tp) * p.C + c0 + c, red[i]);
+        for (int e = 0; e < 4; ++e) {
+          const int k = wk0 + a * 16 + (lane >> 4) * 4 + e, c = wc0 + b * 16 + (lane & 15);
+          if (WS) atomicAdd(red + (k * 9 + tp) * CT + c, acc[t][a][b][e]);
+          else red[(k * 9 + tp) * CT + c] = acc[t][a][b][e];
+        }
+  }
+  __syncthreads();
+  constexpr int C4 = CT / 4;
+  float* const slab = p.slab ? p.slab + (size_t)blockIdx.z * p.K * 9 * p.C : nullptr;
+  for (int i = tid; i < KT * 9 * C4; i += NT) {
+    const int row = i / C4, c4 = i - row * C4;
+    const int k = row / 9, tp = row - k * 9;
+    if (k0 + k >= p.K) continue;
+    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(red + row * CT + c4 * 4);
+    const size_t off = ((size_t)(k0 + k) * 9 + tp) * p.C + c0 + c4 * 4;
+    if (slab) {
+      *reinterpret_cast<f32x4_t*>(slab + off) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(p.dw + off + e, v[e]);
     }
-  } else {
+  }
+}
+
+// dw[e] += sum_s slab[s][e]  in a fixed order (reproducible gradients).  16 float4 elements x 16 split lanes per
+// workgroup: lane ty adds splits ty, ty+16, ... (4 loads in flight), then the 16 partial sums are added in order.
+__global__ __launch_bounds__(256) void k_wgrad_slab_reduce(size_t n4, int splits, const float* __restrict__ slab, float* __restrict__ dw) {
+  __shared__ f32x4_t red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const size_t e = (size_t)blockIdx.x * 16 + tx;
+  f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (e < n4) {
+    int s = ty;
+    for (; s + 48 < splits; s += 64) {
+      const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(slab + ((size_t)s * n4 + e) * 4);
+      const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(slab + ((size_t)(s + 16) * n4 + e) * 4);
+      const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(slab + ((size_t)(s + 32) * n4 + e) * 4);
+      const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(slab + ((size_t)(s + 48) * n4 + e) * 4);
+      a = a + v0; a = a + v1; a = a + v2; a = a + v3;
+    }
+    for (; s < splits; s += 16) a = a + *reinterpret_cast<const f32x4_t*>(slab + ((size_t)s * n4 + e) * 4);
+  }
+  red[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && e < n4) {
+    f32x4_t t = *reinterpret_cast<const f32x4_t*>(dw + 4 * e);
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-      for (int a = 0; a < TK; ++a)
-#pragma unroll
-        for (int b = 0; b < TCc; ++b)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int k = k0 + wk0 + a * 16 + (lane >> 4) * 4 + e, c = c0 + wc0 + b * 16 + (lane & 15);
-            if (k < p.K) atomicAdd(p.dw + ((size_t)k * 9 + tp) * p.C + c, acc[tp][a][b][e]);
-          }
+    for (int j = 0; j < 16; ++j) t = t + red[j][tx];
+    *reinterpret_cast<f32x4_t*>(dw + 4 * e) = t;
   }
 }
 
 // ------------------------------------------------------------------------------------------------ host
 // tuning knobs, read per call so that tests can force the kernel onto small problems
-static int wh_max_combo() { const char* e = getenv("VK_WH_MAXCOMBO"); return e ? atoi(e) : 16; }
-static int wh_min_blocks() { const char* e = getenv("VK_WH_MINBLOCKS"); return e ? atoi(e) : 256; }
+static int wh_max_combo() { const char* e = getenv("VK_WH_MAXCOMBO"); return e ? atoi(e) : 64; }
+static int wh_min_blocks() { const char* e = getenv("VK_WH_MINBLOCKS"); return e ? atoi(e) : 160; }
 
-template <typename T, int KT, int CT, bool WS>
-static int launch_wh(WhParams p, hipStream_t st) {
-  using Cfg = WhCfg<T, KT, CT, WS>;
+template <typename T, int KT, int CT, bool WS, bool TS = false>
+static int launch_wh(WhParams p, size_t slab_bytes, hipStream_t st) {
+  using Cfg = WhCfg<T, KT, CT, WS, TS>;
   p.tiles_x = (p.W + 15) / 16;
   p.tiles_y = (p.H + 7) / 8;
   p.ntiles = p.N * p.tiles_y * p.tiles_x;
@@ -290,43 +368,53 @@ static int launch_wh(WhParams p, hipStream_t st) {
   if (kt * ct > wh_max_combo()) return VK_ERR_UNSUPPORTED;      // deep layers: output tile traffic would dominate
   // every workgroup ends with KT*CT*9 fp32 atomics: give it at least ~6 pixel tiles of work
   const char* e_blk = getenv("VK_WH_BLOCKS");
-  const int target_blocks = e_blk ? atoi(e_blk) : (WS ? 1024 : 320);
-  int splits = (target_blocks + kt * ct - 1) / (kt * ct);
+  const int target_blocks = e_blk ? atoi(e_blk) : (WS ? 1024 : 256);       // non-WS: LDS allows exactly one workgroup per CU
+  int splits = target_blocks / (kt * ct);     // never exceed the target: a second round of workgroups costs a full round
   if (splits > p.ntiles / 6) splits = p.ntiles / 6;
   if (splits < 1) splits = 1;
   if ((long)splits * kt * ct < wh_min_blocks()) return VK_ERR_UNSUPPORTED;  // too few workgroups to fill the chip
   p.splits = splits;
+  p.dbg_skip_epilogue = getenv("VK_WH_DBG_NOEPI") ? 1 : 0;
+  const size_t slab_need = (size_t)splits * p.K * 9 * p.C * sizeof(float);
+  if (!p.slab || slab_need > slab_bytes || getenv("VK_WH_NO_SLAB")) p.slab = nullptr;
   dim3 grid(kt, ct, splits);
   static bool attr_done = false;
   if (!attr_done && Cfg::SMEM > 64 * 1024) {
-    VK_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<T, KT, CT, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<T, KT, CT, WS, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
     attr_done = true;
   }
   {
-    static const std::string tag = std::string("wgrad_halo_") + (sizeof(T) == 4 ? "f32" : "16b") + "_" + std::to_string(KT) + "x" + std::to_string(CT);
+    static const std::string tag = std::string("wgrad_halo_") + (sizeof(T) == 4 ? "f32" : "16b") + "_" + std::to_string(KT) + "x" + std::to_string(CT) + (TS ? "ts" : "");
     const double bytes = (double)p.N * p.H * p.W * (p.C + p.K) * sizeof(T) + 9.0 * p.K * p.C * 4.0;
     const std::string dtag = getenv("VK_PROF_DETAIL") ? tag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) + "_s" + std::to_string(splits) : tag;
     vkh::ProfScope ps(dtag.c_str(), st, 2.0 * (double)p.N * p.H * p.W * p.K * 9.0 * p.C, bytes);
-    hipLaunchKernelGGL((wgrad_halo_kernel<T, KT, CT, WS>), grid, dim3(256), Cfg::SMEM, st, p);
+    hipLaunchKernelGGL((wgrad_halo_kernel<T, KT, CT, WS, TS>), grid, dim3(Cfg::NT), Cfg::SMEM, st, p);
+    if (p.slab) {
+      const size_t n4 = (size_t)p.K * 9 * p.C / 4;
+      hipLaunchKernelGGL(k_wgrad_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, n4, splits, p.slab, p.dw);
+    }
   }
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }
 
 template <typename T>
-static int wh_select(const WhParams& p, int cgran, hipStream_t st) {
+static int wh_select(const WhParams& p, int cgran, size_t slab_bytes, hipStream_t st) {
   // cgran: channel granularity that keeps a c-tile inside one concat source
   if constexpr (sizeof(T) == 2) {      // fp32 double-buffered 64x64 stages would need 197 KB of LDS
-    if (p.K >= 64 && cgran % 64 == 0) return launch_wh<T, 64, 64, false>(p, st);
+    if (p.K >= 64 && cgran % 64 == 0) {
+      if (getenv("VK_WH_NO_TS")) return launch_wh<T, 64, 64, false>(p, slab_bytes, st);
+      return launch_wh<T, 64, 64, false, true>(p, slab_bytes, st);
+    }
   }
-  if (p.K >= 32 && cgran % 32 == 0) return launch_wh<T, 32, 32, true>(p, st);
-  if (p.K >= 16 && cgran % 32 == 0) return launch_wh<T, 16, 32, true>(p, st);
-  if (p.K >= 16 && cgran % 16 == 0) return launch_wh<T, 16, 16, true>(p, st);
+  if (p.K >= 32 && cgran % 32 == 0) return launch_wh<T, 32, 32, true>(p, slab_bytes, st);
+  if (p.K >= 16 && cgran % 32 == 0) return launch_wh<T, 16, 32, true>(p, slab_bytes, st);
+  if (p.K >= 16 && cgran % 16 == 0) return launch_wh<T, 16, 16, true>(p, slab_bytes, st);
   return VK_ERR_UNSUPPORTED;
 }
 
 // returns VK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the tap-by-tap kernel)
-int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, hipStream_t st) {
+int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->H != d->Ho || d->W != d->Wo) return VK_ERR_UNSUPPORTED;
   if (getenv("VK_NO_WGRAD_HALO")) return VK_ERR_UNSUPPORTED;
   const int eb = d->dtype == VK_F32 ? 4 : 2;
@@ -350,10 +438,12 @@ int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, hipStream_t
   p.dw = dw;
   p.N = d->N; p.H = d->H; p.W = d->W; p.K = d->K; p.C = C;
   p.tiles_x = p.tiles_y = p.ntiles = p.splits = 0;
+  p.dbg_skip_epilogue = 0;
+  p.slab = (float*)workspace;
   switch (d->dtype) {
-    case VK_F32: return wh_select<float>(p, cgran, st);
-    case VK_BF16: return wh_select<bf16_t>(p, cgran, st);
-    case VK_F16: return wh_select<f16_t>(p, cgran, st);
+    case VK_F32: return wh_select<float>(p, cgran, workspace_bytes, st);
+    case VK_BF16: return wh_select<bf16_t>(p, cgran, workspace_bytes, st);
+    case VK_F16: return wh_select<f16_t>(p, cgran, workspace_bytes, st);
   }
   return VK_ERR_ARG;
 }
