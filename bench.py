@@ -58,7 +58,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    force_dist = bool(os.environ.get("VK_BENCH_FORCE_DIST"))      # exercise the RCCL path with a single rank (testing)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -71,8 +72,8 @@ def main():
     O.set_seed(42)
     model = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev)
     opt = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
-    if world > 1:
-        vk.make_data_parallel(model, opt)
+    if world > 1 or force_dist:
+        vk.make_data_parallel(model, opt, force=force_dist)
     x, y = O.synthetic_batch(N, S, seed=1234 + rank)      # rank r owns images [r*N, (r+1)*N)
     x, y = x.to(dev), y.to(dev)
     _log(f"rank {rank}/{world}: model + data resident on {torch.cuda.get_device_name(dev)}")
@@ -94,7 +95,7 @@ def main():
                 return model(x)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier(device_ids=[local_rank])
 
     for i in range(args.warmup):
@@ -114,7 +115,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     _log(f"timed region: {dt / args.steps * 1e3:.2f} ms/step")
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -202,7 +203,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -134,6 +134,12 @@ int vk_bn_bwd_coeffs(int C, const double* sums, double count, const float* gamma
 int vk_bn_bwd_apply(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
                     const float* scale, const float* shift, const void* mask_src, const float* coef_abc, void* dz,
                     void* g_out, int g_accumulate, void* stream);
+/* phase 2 with vk_bn_bwd_coeffs folded in: coefficients are derived from `sums` inside the kernel and
+ * dgamma/dbeta are accumulated by it (one launch less per BatchNorm layer). */
+int vk_bn_bwd_apply_fused(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
+                          const float* scale, const float* shift, const void* mask_src, const double* sums, double count,
+                          const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                          void* dz, void* g_out, int g_accumulate, void* stream);
 
 /* d_low[N][H/2][W/2][C] (+)= 2x2 sums of d_up[N][H][W][C] (nearest-x2 upsample backward) */
 int vk_upsample2x_bwd(vk_dtype dtype, int N, int H, int W, int C, const void* d_up, void* d_low, int accumulate,

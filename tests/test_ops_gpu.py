@@ -462,6 +462,17 @@ def test_bn_relu_backward(dtn, mask_mode):
     assert (from_nhwc(dz) - ref).abs().max().item() <= (2e-4 if dt == torch.float32 else 2e-2) * ref.abs().max().item()
     gref = dy * (out.detach().float() > 0)
     assert (from_nhwc(gout) - gref).abs().max().item() <= tol(dt, gref)
+    # fused variant: coefficients + dgamma/dbeta computed inside the apply kernel
+    dgam2, dbet2 = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
+    dz2 = torch.empty_like(zd)
+    gout2 = torch.zeros_like(zd)
+    vk._lib.check(vk.lib().vk_bn_bwd_apply_fused(code, N * H * H, Cc, dyd.data_ptr(), zd.data_ptr(), mask_mode, scale.data_ptr(), shift.data_ptr(),
+                                                 outd.data_ptr(), sums.data_ptr(), cnt, D(gamma).data_ptr(), D(mean.float()).data_ptr(),
+                                                 D(invstd.float()).data_ptr(), dgam2.data_ptr(), dbet2.data_ptr(), dz2.data_ptr(), gout2.data_ptr(), 0, st()))
+    torch.cuda.synchronize()
+    assert torch.allclose(dgam2, dgam, rtol=1e-6, atol=1e-7) and torch.allclose(dbet2, dbet, rtol=1e-6, atol=1e-7)
+    assert (dz2.float() - dz.float()).abs().max().item() <= 1e-6 * ref.abs().max().item() + (0 if dt == torch.float32 else 1e-2 * ref.abs().max().item())
+    assert torch.equal(gout2, gout)
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])

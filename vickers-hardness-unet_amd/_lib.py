@@ -62,6 +62,7 @@ SIGNATURES = {
     "vk_bn_bwd_reduce": (ci, [ci, sz, ci, vp, vp, ci, vp, vp, vp, vp, vp]),
     "vk_bn_bwd_coeffs": (ci, [ci, vp, cd, vp, vp, vp, vp, vp, vp, vp]),
     "vk_bn_bwd_apply": (ci, [ci, sz, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
+    "vk_bn_bwd_apply_fused": (ci, [ci, sz, ci, vp, vp, ci, vp, vp, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
     "vk_upsample2x_bwd": (ci, [ci, ci, ci, ci, ci, vp, vp, ci, vp]),
     "vk_head_fwd": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp]),
     "vk_head_bwd": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp, vp, vp]),

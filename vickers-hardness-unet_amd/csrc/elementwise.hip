@@ -35,19 +35,27 @@ __global__ void k_input_transform(int N, int H, int W, const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // K5: BatchNorm statistics -> affine
-__global__ void k_bn_finalize(int C, int train, const double* __restrict__ stats, double count,
-                              const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
-                              float* running_var, float eps, float momentum, float* scale, float* shift,
-                              float* save_mean, float* save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void k_bn_finalize(int C, int train, const double* __restrict__ stats, double count,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                                     float* running_var, float eps, float momentum, float* scale, float* shift,
+                                                     float* save_mean, float* save_invstd) {
+  // 8 channels per workgroup; the 32 lanes of a half-wave each fetch one replica of the partial sums
+  static_assert(VK_STATS_REPLICAS == 32, "lane mapping assumes 32 replicas");
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int r = threadIdx.x & 31;
+  double s1 = 0.0, s2 = 0.0;
+  if (train && c < C) {
+    s1 = stats[(size_t)r * 2 * C + c];
+    s2 = stats[(size_t)r * 2 * C + C + c];
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (r != 0 || c >= C) return;
   double mean, var;
   if (train) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < VK_STATS_REPLICAS; ++r) {
-      s1 += stats[(size_t)r * 2 * C + c];
-      s2 += stats[(size_t)r * 2 * C + C + c];
-    }
     mean = s1 / count;
     var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -184,24 +192,45 @@ __global__ void k_maxpool_bwd(int N, int H, int W, int C, const T* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // K6: BasicBlock tail  out = relu(bn2(z) + shortcut)
 template <typename T>
-__global__ void k_bn_add_relu(size_t pixels, int C, const T* __restrict__ z, const float* __restrict__ scale,
-                              const float* __restrict__ shift, const T* __restrict__ res, const float* __restrict__ rscale,
-                              const float* __restrict__ rshift, T* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_bn_add_relu(size_t pixels, int C, const T* __restrict__ z, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const T* __restrict__ res, const float* __restrict__ rscale,
+                                                     const float* __restrict__ rshift, T* __restrict__ out) {
   constexpr int VE = ElemTraits<T>::kVec;
+  constexpr int U = 4;                                   // independent 16-byte loads in flight per operand
   const int CV = C / VE;
   const size_t total = pixels * CV;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % CV) * VE;
-    float f[VE], r[VE];
-    Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(z + i * VE), f);
-    Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(res + i * VE), r);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;  // multiple of CV => the channel group of a thread is fixed
+  const size_t t0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const int c0 = (int)(t0 % CV) * VE;
+  float sc[VE], sh[VE], rsc[VE], rsh[VE];
 #pragma unroll
-    for (int j = 0; j < VE; ++j) {
-      float v = fmaf(f[j], scale[c0 + j], shift[c0 + j]);
-      const float rr = rscale ? fmaf(r[j], rscale[c0 + j], rshift[c0 + j]) : r[j];
-      f[j] = fmaxf(v + rr, 0.f);
+  for (int j = 0; j < VE; ++j) {
+    sc[j] = scale[c0 + j];
+    sh[j] = shift[c0 + j];
+    rsc[j] = rscale ? rscale[c0 + j] : 1.f;
+    rsh[j] = rscale ? rshift[c0 + j] : 0.f;
+  }
+  for (size_t i = t0; i < total; i += U * stride) {
+    u32x4_t zv[U], rv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t k = i + u * stride;
+      if (k < total) {
+        zv[u] = *reinterpret_cast<const u32x4_t*>(z + k * VE);
+        rv[u] = *reinterpret_cast<const u32x4_t*>(res + k * VE);
+      }
     }
-    *reinterpret_cast<u32x4_t*>(out + i * VE) = Vec16<T>::pack(f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t k = i + u * stride;
+      if (k >= total) continue;
+      float f[VE], r[VE];
+      Vec16<T>::unpack(zv[u], f);
+      Vec16<T>::unpack(rv[u], r);
+#pragma unroll
+      for (int j = 0; j < VE; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]) + fmaf(r[j], rsc[j], rsh[j]), 0.f);
+      *reinterpret_cast<u32x4_t*>(out + k * VE) = Vec16<T>::pack(f);
+    }
   }
 }
 
@@ -304,35 +333,80 @@ __global__ void k_bn_bwd_coeffs(int C, const double* __restrict__ sums, double c
   coef[2 * C + c] = (float)cc;
 }
 
+// dz = a*g + b*z + c with (a, b, c) derived in-kernel from the reduction sums:
+//   dgamma = r*(S_gz - mu*S_g), dbeta = S_g, a = gamma*r, b = -gamma*r^2*dgamma/M, c = -a*dbeta/M - b*mu
+// Workgroup 0 also accumulates dgamma/dbeta into the flat gradient buffer (coef == nullptr: fused mode).
 template <typename T, int MASK>
-__global__ void k_bn_bwd_apply(size_t pixels, int C, const T* __restrict__ dy, const T* __restrict__ z,
-                               const float* __restrict__ scale, const float* __restrict__ shift, const T* __restrict__ mask_src,
-                               const float* __restrict__ coef, T* __restrict__ dz, T* g_out, int g_acc) {
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(size_t pixels, int C, const T* __restrict__ dy, const T* __restrict__ z,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift, const T* __restrict__ mask_src,
+                                                      const float* __restrict__ coef, const double* __restrict__ sums, double count,
+                                                      const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                      const float* __restrict__ save_invstd, float* dgamma, float* dbeta, T* __restrict__ dz, T* g_out,
+                                                      int g_acc) {
   constexpr int VE = ElemTraits<T>::kVec;
+  constexpr int U = 2;
   const int CV = C / VE;
   const size_t total = pixels * CV;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % CV) * VE;
-    float sc[VE], sh[VE];
-#pragma unroll
-    for (int j = 0; j < VE; ++j) {
-      sc[j] = (MASK == 1) ? scale[c0 + j] : 1.f;
-      sh[j] = (MASK == 1) ? shift[c0 + j] : 0.f;
-    }
-    float g[VE], zf[VE], o[VE];
-    masked_grad<T, MASK>(dy, z, mask_src, i * VE, sc, sh, g, zf);
-#pragma unroll
-    for (int j = 0; j < VE; ++j) o[j] = fmaf(coef[c0 + j], g[j], fmaf(coef[C + c0 + j], zf[j], coef[2 * C + c0 + j]));
-    *reinterpret_cast<u32x4_t*>(dz + i * VE) = Vec16<T>::pack(o);
-    if (g_out) {
-      u32x4_t* gp = reinterpret_cast<u32x4_t*>(g_out + i * VE);
-      if (g_acc) {
-        float old[VE];
-        Vec16<T>::unpack(*gp, old);
-#pragma unroll
-        for (int j = 0; j < VE; ++j) g[j] += old[j];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;   // multiple of CV
+  const size_t t0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const int c0 = (int)(t0 % CV) * VE;
+  // per-workgroup coefficient table in LDS (one thread per channel), so the per-thread prologue is 3 LDS reads / channel
+  __shared__ float cf[3][512];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    if (coef) {
+      cf[0][c] = coef[c];
+      cf[1][c] = coef[C + c];
+      cf[2][c] = coef[2 * C + c];
+    } else {
+      // only the cancelling difference needs fp64 (one DFMA per channel); the rest is fp32
+      const float mu = save_mean[c], r = save_invstd[c], ga = gamma[c];
+      const double sg = sums[c];
+      const float d = (float)(sums[C + c] - (double)mu * sg);
+      const float sgf = (float)sg, inv = (float)(1.0 / count);
+      const float dg = r * d;
+      const float a = ga * r, b = -a * r * dg * inv;
+      cf[0][c] = a;
+      cf[1][c] = b;
+      cf[2][c] = -a * sgf * inv - b * mu;
+      if (blockIdx.x == 0) {
+        dgamma[c] += dg;
+        dbeta[c] += sgf;
       }
-      *gp = Vec16<T>::pack(g);
+    }
+  }
+  __syncthreads();
+  float sc[VE], sh[VE], ca[VE], cb[VE], cc[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) {
+    sc[j] = (MASK == 1) ? scale[c0 + j] : 1.f;
+    sh[j] = (MASK == 1) ? shift[c0 + j] : 0.f;
+    ca[j] = cf[0][c0 + j];
+    cb[j] = cf[1][c0 + j];
+    cc[j] = cf[2][c0 + j];
+  }
+  for (size_t i = t0; i < total; i += U * stride) {
+    float g[U][VE], zf[U][VE];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i + u * stride < total) masked_grad<T, MASK>(dy, z, mask_src, (i + u * stride) * VE, sc, sh, g[u], zf[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t k = i + u * stride;
+      if (k >= total) continue;
+      float o[VE];
+#pragma unroll
+      for (int j = 0; j < VE; ++j) o[j] = fmaf(ca[j], g[u][j], fmaf(cb[j], zf[u][j], cc[j]));
+      *reinterpret_cast<u32x4_t*>(dz + k * VE) = Vec16<T>::pack(o);
+      if (g_out) {
+        u32x4_t* gp = reinterpret_cast<u32x4_t*>(g_out + k * VE);
+        if (g_acc) {
+          float old[VE];
+          Vec16<T>::unpack(*gp, old);
+#pragma unroll
+          for (int j = 0; j < VE; ++j) g[u][j] += old[j];
+        }
+        *gp = Vec16<T>::pack(g[u]);
+      }
     }
   }
 }
@@ -611,7 +685,7 @@ extern "C" int vk_bn_finalize(int C, int train, const double* stats, double coun
   VK_CHECK_ARG(C > 0 && gamma && beta && scale && shift, "vk_bn_finalize: null argument");
   VK_CHECK_ARG(train ? (stats != nullptr && count > 0) : (running_mean && running_var), "vk_bn_finalize: missing statistics");
   vkh::ProfScope ps_("bn_finalize", (hipStream_t)stream, 0.0, (double)C * 40.0);
-  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, train, stats, count, gamma, beta,
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, C, train, stats, count, gamma, beta,
                      running_mean, running_var, eps, momentum, scale, shift, save_mean, save_invstd);
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
@@ -691,29 +765,53 @@ extern "C" int vk_bn_bwd_coeffs(int C, const double* sums, double count, const f
   return VK_OK;
 }
 
+struct BnApplyArgs {
+  size_t pixels; int C; const void* dy; const void* z; int mask_mode; const float* scale; const float* shift; const void* mask_src;
+  const float* coef; const double* sums; double count; const float* gamma; const float* mean; const float* invstd; float* dgamma; float* dbeta;
+  void* dz; void* g_out; int g_acc;
+};
+
 template <typename T>
-static int launch_bn_bwd_apply(size_t pixels, int C, const void* dy, const void* z, int mask_mode, const float* scale,
-                               const float* shift, const void* mask_src, const float* coef, void* dz, void* g_out, int g_acc,
-                               hipStream_t st) {
-  dim3 grid(grid_for(pixels * (C / ElemTraits<T>::kVec))), block(256);
-  if (mask_mode == 0) hipLaunchKernelGGL((k_bn_bwd_apply<T, 0>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, coef, (T*)dz, (T*)g_out, g_acc);
-  else if (mask_mode == 1) hipLaunchKernelGGL((k_bn_bwd_apply<T, 1>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, coef, (T*)dz, (T*)g_out, g_acc);
-  else hipLaunchKernelGGL((k_bn_bwd_apply<T, 2>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, coef, (T*)dz, (T*)g_out, g_acc);
+static int launch_bn_bwd_apply(const BnApplyArgs& a, hipStream_t st) {
+  const int CV = a.C / ElemTraits<T>::kVec;
+  // grid * 256 must be a multiple of CV (<= 128): any block count works; keep enough blocks to fill the chip
+  dim3 grid(grid_for(a.pixels * CV / 2 + 1)), block(256);
+#define VK_APPLY(M) hipLaunchKernelGGL((k_bn_bwd_apply<T, M>), grid, block, 0, st, a.pixels, a.C, (const T*)a.dy, (const T*)a.z, a.scale, a.shift, \
+    (const T*)a.mask_src, a.coef, a.sums, a.count, a.gamma, a.mean, a.invstd, a.dgamma, a.dbeta, (T*)a.dz, (T*)a.g_out, a.g_acc)
+  if (a.mask_mode == 0) VK_APPLY(0);
+  else if (a.mask_mode == 1) VK_APPLY(1);
+  else VK_APPLY(2);
+#undef VK_APPLY
+  return VK_OK;
+}
+
+static int bn_bwd_apply_common(vk_dtype dtype, const BnApplyArgs& a, void* stream) {
+  VK_CHECK_ARG(a.dy && a.z && a.dz && (a.coef || (a.sums && a.gamma && a.mean && a.invstd && a.dgamma && a.dbeta)), "vk_bn_bwd_apply: null argument");
+  VK_CHECK_ARG(a.mask_mode >= 0 && a.mask_mode <= 2, "vk_bn_bwd_apply: mask_mode %d", a.mask_mode);
+  VK_CHECK_ARG(a.mask_mode != 1 || (a.scale && a.shift), "vk_bn_bwd_apply: mask_mode 1 needs scale/shift");
+  VK_CHECK_ARG(a.mask_mode != 2 || a.mask_src, "vk_bn_bwd_apply: mask_mode 2 needs mask_src");
+  VK_CHECK_ARG(a.C <= 512 && a.C % 8 == 0, "vk_bn_bwd_apply: C=%d unsupported", a.C);
+  hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("bn_bwd_apply", st, 0.0, (double)a.pixels * a.C * (dtype == VK_F32 ? 4.0 : 2.0) * ((a.mask_mode == 2 ? 4.0 : 3.0) + (a.g_out ? (a.g_acc ? 2.0 : 1.0) : 0.0)));
+  DISPATCH_T(dtype, launch_bn_bwd_apply<T>(a, st));
+  VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }
 
 extern "C" int vk_bn_bwd_apply(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
                                const float* scale, const float* shift, const void* mask_src, const float* coef_abc, void* dz,
                                void* g_out, int g_accumulate, void* stream) {
-  VK_CHECK_ARG(dy && z && coef_abc && dz, "vk_bn_bwd_apply: null argument");
-  VK_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "vk_bn_bwd_apply: mask_mode %d", mask_mode);
-  VK_CHECK_ARG(mask_mode != 1 || (scale && shift), "vk_bn_bwd_apply: mask_mode 1 needs scale/shift");
-  VK_CHECK_ARG(mask_mode != 2 || mask_src, "vk_bn_bwd_apply: mask_mode 2 needs mask_src");
-  hipStream_t st = (hipStream_t)stream;
-  vkh::ProfScope ps_("bn_bwd_apply", st, 0.0, (double)pixels * C * (dtype == VK_F32 ? 4.0 : 2.0) * ((mask_mode == 2 ? 4.0 : 3.0) + (g_out ? (g_accumulate ? 2.0 : 1.0) : 0.0)));
-  DISPATCH_T(dtype, launch_bn_bwd_apply<T>(pixels, C, dy, z, mask_mode, scale, shift, mask_src, coef_abc, dz, g_out, g_accumulate, st));
-  VK_CHECK_HIP(hipGetLastError());
-  return VK_OK;
+  VK_CHECK_ARG(coef_abc, "vk_bn_bwd_apply: null coefficients");
+  BnApplyArgs a{pixels, C, dy, z, mask_mode, scale, shift, mask_src, coef_abc, nullptr, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, dz, g_out, g_accumulate};
+  return bn_bwd_apply_common(dtype, a, stream);
+}
+
+extern "C" int vk_bn_bwd_apply_fused(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
+                                     const float* scale, const float* shift, const void* mask_src, const double* sums, double count,
+                                     const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                                     void* dz, void* g_out, int g_accumulate, void* stream) {
+  BnApplyArgs a{pixels, C, dy, z, mask_mode, scale, shift, mask_src, nullptr, sums, count, gamma, save_mean, save_invstd, dgamma, dbeta, dz, g_out, g_accumulate};
+  return bn_bwd_apply_common(dtype, a, stream);
 }
 
 extern "C" int vk_upsample2x_bwd(vk_dtype dtype, int N, int H, int W, int C, const void* d_up, void* d_low, int accumulate,

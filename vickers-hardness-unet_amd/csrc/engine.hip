@@ -741,8 +741,8 @@ int bn_relu_bwd_inplace(vk_unet* h, ConvL& c, hipStream_t st) {
   BnL& b = h->bns[c.bn];
   const size_t pixels = (size_t)h->cfg.N * c.Hout * c.Hout;
   RET_IF(vk_bn_bwd_reduce(h->cfg.dtype, pixels, c.K, c.g, c.z, 1, b.scale, b.shift, nullptr, b.bsums, st));
-  RET_IF(vk_bn_bwd_coeffs(c.K, b.bsums, b.count, h->params + b.g_off, b.mean, b.invstd, h->grads + b.g_off, h->grads + b.b_off, b.coef, st));
-  return vk_bn_bwd_apply(h->cfg.dtype, pixels, c.K, c.g, c.z, 1, b.scale, b.shift, nullptr, b.coef, c.g, nullptr, 0, st);
+  return vk_bn_bwd_apply_fused(h->cfg.dtype, pixels, c.K, c.g, c.z, 1, b.scale, b.shift, nullptr, b.bsums, b.count, h->params + b.g_off, b.mean,
+                               b.invstd, h->grads + b.g_off, h->grads + b.b_off, c.g, nullptr, 0, st);
 }
 
 int conv_wgrad(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, hipStream_t st) {
@@ -823,17 +823,18 @@ int backward_block(vk_unet* h, int bi, hipStream_t st) {
   }
   // tail: out = relu(bn2(z2) + shortcut);  g = gout * (out > 0)
   RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.bsums, st));
-  RET_IF(vk_bn_bwd_coeffs(k.C, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd, h->grads + b2.g_off, h->grads + b2.b_off, b2.coef, st));
   if (k.convd < 0) {
     // identity shortcut: gin (+)= g
-    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.coef, c2.g, gin, k.in_has_grad_first ? 1 : 0, st));
+    RET_IF(vk_bn_bwd_apply_fused(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd,
+                                 h->grads + b2.g_off, h->grads + b2.b_off, c2.g, gin, k.in_has_grad_first ? 1 : 0, st));
   } else {
     ConvL& cd = h->convs[k.convd];
     BnL& bd = h->bns[cd.bn];
-    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.coef, c2.g, nullptr, 0, st));
+    RET_IF(vk_bn_bwd_apply_fused(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd,
+                                 h->grads + b2.g_off, h->grads + b2.b_off, c2.g, nullptr, 0, st));
     RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, cd.z, 2, nullptr, nullptr, k.out, bd.bsums, st));
-    RET_IF(vk_bn_bwd_coeffs(k.C, bd.bsums, bd.count, h->params + bd.g_off, bd.mean, bd.invstd, h->grads + bd.g_off, h->grads + bd.b_off, bd.coef, st));
-    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, cd.z, 2, nullptr, nullptr, k.out, bd.coef, cd.g, nullptr, 0, st));
+    RET_IF(vk_bn_bwd_apply_fused(dt, pixels, k.C, k.gout, cd.z, 2, nullptr, nullptr, k.out, bd.bsums, bd.count, h->params + bd.g_off, bd.mean, bd.invstd,
+                                 h->grads + bd.g_off, h->grads + bd.b_off, cd.g, nullptr, 0, st));
   }
   // conv2
   RET_IF(conv_wgrad(h, c2, to_src(bn_act(h, c1)), null_src(), st));

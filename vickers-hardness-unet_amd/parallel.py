@@ -24,14 +24,14 @@ import torch.distributed as dist
 
 class GradientReducer:
     def __init__(self, flat_grads_getter, world_size: Optional[int] = None, process_group=None,
-                 scale_grads: bool = False):
+                 scale_grads: bool = False, force: bool = False):
         self._get = flat_grads_getter
         self.pg = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         self.scale_grads = scale_grads
         self._handles: List = []
         self._ranges: List[Tuple[int, int]] = []
-        self.enabled = self.world > 1
+        self.enabled = self.world > 1 or force        # force: run the collectives even with one rank (testing)
 
     @property
     def inv_world(self) -> float:
@@ -60,17 +60,17 @@ class GradientReducer:
 
 def broadcast_model(model, src: int = 0, process_group=None):
     """Rank-0 parameters and BatchNorm buffers to every rank (three flat tensors, three collectives)."""
-    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+    if not dist.is_initialized():
         return
     for k in ("params", "bufs", "nbt"):
         dist.broadcast(model._flat[k], src=src, group=process_group)
     model.mark_weights_dirty()
 
 
-def make_data_parallel(model, optimizer=None, process_group=None) -> GradientReducer:
+def make_data_parallel(model, optimizer=None, process_group=None, force: bool = False) -> GradientReducer:
     """Attach a GradientReducer to ``model``; with a FusedAdamW the averaging is folded into its kernel."""
     fold = optimizer is not None and hasattr(optimizer, "grad_inv_scale")
-    red = GradientReducer(lambda: model.flat_grads, process_group=process_group, scale_grads=not fold)
+    red = GradientReducer(lambda: model.flat_grads, process_group=process_group, scale_grads=not fold, force=force)
     if fold:
         optimizer.grad_inv_scale = red.inv_world
     model._reducer = red
