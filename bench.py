@@ -137,7 +137,7 @@ def main():
             dom = max(table.items(), key=lambda kv: kv[1]["ms"])
             tag, r = dom
             per_launch_ms = r["ms"] / r["n"]
-            if r["flops"] > 0 and ("igemm" in tag or "wgrad" in tag or "stem" in tag):
+            if r["flops"] > 0 and any(k in tag for k in ("igemm", "wgrad", "stem", "halo")):
                 peak = PEAK_MFMA_F32 if "f32" in tag else PEAK_MFMA_16B
                 ach = r["flops"] / (r["ms"] * 1e-3)
                 roof = {"kernel": tag, "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
@@ -161,14 +161,14 @@ def main():
         _log(f"cpu baseline on {cores} threads ...")
         O.set_seed(42)
         ref = O.build_model()
-        bs = 2
+        bs = 4
         xc, yc = O.synthetic_batch(bs, S, seed=1234)
         if args.mode == "train":
             ref.train()
             ropt = torch.optim.AdamW(ref.parameters(), lr=5e-5, weight_decay=1e-4)
             O.train_steps(ref, ropt, [(xc, yc)])                  # warm-up
             t1 = time.perf_counter()
-            nst = 2
+            nst = 8                                                # ~10-20 s of CPU work on a 16-core share
             O.train_steps(ref, ropt, [(xc, yc)] * nst)
             cdt = time.perf_counter() - t1
             sample = f"{nst} fp32 train steps (fwd+loss+bwd+AdamW, per-step loss.item()) at bs={bs}, {S}x{S}, after 1 warm-up"
@@ -177,7 +177,7 @@ def main():
             with torch.no_grad():
                 ref(xc)
                 t1 = time.perf_counter()
-                nst = 3
+                nst = 12
                 for _ in range(nst):
                     ref(xc)
                 cdt = time.perf_counter() - t1

@@ -220,3 +220,77 @@ def test_reference_style_epoch_with_amp(pair):
     assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1 + 0.05
     vl, vd, vi = vk.validate(model, loader, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda")
     assert np.isfinite(vl) and 0.0 <= vd <= 1.0 and 0.0 <= vi <= 1.0
+
+
+def test_config2_fp32_eval_bs16_512_full_size(pair):
+    """BASELINE.json configs[1] at its real size: fp32 forward-only, bs=16, 512x512 — logits within 1e-3 of the CPU
+    oracle and mask IoU / Dice within 1e-4 (north_star tolerances).
+    The BN running statistics are first calibrated on the oracle (one train-mode pass with momentum 1, i.e. running
+    stats = batch stats) and loaded through load_state_dict, which is the state an inference checkpoint is in; with the
+    untouched defaults (mean 0 / var 1) eval-mode BN normalises nothing, the activations of a random-init net grow to
+    |logit| ~ 1e2 and the 1e-3 ABSOLUTE bar degenerates into fp32 round-off (we then check 1e-4 RELATIVE instead)."""
+    O, _, _ = pair
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    O.set_seed(42); ref = O.build_model()
+    model = vk.Unet(encoder_weights=None).to(dev())
+    x, y = O.synthetic_batch(16, 512, seed=1234)
+    # (a) default running stats: relative bar
+    model.load_state_dict(ref.state_dict(), strict=True)
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        lo = ref(x)
+        lg = model(x.to(dev())).cpu()
+    assert (lg - lo).abs().max().item() <= 1e-4 * lo.abs().max().item()
+    # (b) calibrated running stats: the absolute north-star bars
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    ref.train()
+    with torch.no_grad():
+        ref(x[:4])
+    ref.eval()
+    model.load_state_dict(ref.state_dict(), strict=True)
+    with torch.no_grad():
+        lo = ref(x)
+        lg = model(x.to(dev())).cpu()
+    assert (lg - lo).abs().max().item() <= 1e-3
+    po, pg = torch.sigmoid(lo), torch.sigmoid(lg)
+    assert abs(O.iou_coef(pg, y) - O.iou_coef(po, y)) <= 1e-4
+    assert abs(O.dice_coef(pg, y) - O.dice_coef(po, y)) <= 1e-4
+    assert (pg > 0.5).eq(po > 0.5).float().mean().item() > 0.99999     # thresholded masks agree with the reference masks
+
+
+def test_config3_bf16_train_bs32_512_properties():
+    """BASELINE.json configs[2] at its real size (bs=32, 512x512, bf16): size-independent properties —
+    finite loss in the expected band, bit-identical forward on repetition, reproducible slab-reduced weight gradients,
+    loss decreases over a few AdamW steps, BN counters advance."""
+    from oracle import unet_oracle as O
+    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
+    opt = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
+    x, y = O.synthetic_batch(32, 512, seed=1234)
+    x, y = x.to(dev()), y.to(dev())
+    model.train()
+    opt.zero_grad(set_to_none=True)
+    l1 = model.loss_and_backward(x, y, dtype=torch.bfloat16).clone()
+    lg1 = model.last_logits.clone()
+    g1 = model.flat_grads.clone()
+    opt.zero_grad(set_to_none=True)
+    l2 = model.loss_and_backward(x, y, dtype=torch.bfloat16).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(l1).all() and 0.5 < l1[0].item() < 4.0          # BCE+Dice at init (reference epoch-1 log: 1.73)
+    assert l1[0].item() == pytest.approx(l1[1].item() + l1[2].item(), rel=1e-6)
+    assert torch.equal(lg1, model.last_logits)                            # forward has no atomics on data: bit-identical
+    assert torch.equal(l1, l2)
+    name_to_off = {t[0]: (t[3], t[4]) for t in model._table}
+    for k in ("encoder.layer1.0.conv1.weight", "encoder.layer3.2.conv2.weight", "decoder.blocks.1.conv1.0.weight"):
+        o, n = name_to_off[k]
+        assert torch.equal(g1[o:o + n], model.flat_grads[o:o + n]), k       # slab-reduced layers: fixed summation order
+    rel = (model.flat_grads - g1).abs().max().item() / g1.abs().max().item()
+    assert rel < 1e-3                                                       # remaining layers use fp32 atomics (order noise only)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad(set_to_none=True)
+        losses.append(model.loss_and_backward(x, y, dtype=torch.bfloat16)[0].item())
+        opt.step()
+    assert losses[-1] < losses[0]
+    assert int(model.state_dict()["encoder.bn1.num_batches_tracked"]) == 6
