@@ -91,6 +91,14 @@ typedef struct {
 int vk_conv_fwd(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate,
                 double* stats, void* stream);
 
+/* Data gradient of a decoder conv1 with the nearest-x2 upsample backward fused in: like vk_conv_fwd with
+ * transposed=1, but the first output part (channels [0, split_k1), or all K when split_k1 == 0) is summed over
+ * 2x2 pixel groups and written to y_half [N][Ho/2][Wo/2][.]; the skip part still goes to y1 at full resolution.
+ * Returns VK_ERR_UNSUPPORTED for shapes outside the 3x3 stride-1 tile kernels (caller then uses
+ * vk_conv_fwd + vk_upsample2x_bwd). */
+int vk_conv_dgrad_pool2(const vk_conv_desc* d, const void* w, void* y_half, void* y1, int split_k1, int accumulate,
+                        void* stream);
+
 /* Stem: 7x7 stride-2 pad-3 convolution of x4 [N][H][W][4] (channel 3 is zero padding) with packed
  * weights wp [64][7][32] (tap row r, 8 columns x 4 channels, zero padded). */
 int vk_stem_fwd(vk_dtype dtype, int N, int H, int W, const void* x4, const void* wp, void* y, double* stats,

@@ -241,6 +241,33 @@ def test_conv_dgrad_split(dtn):
     assert (from_nhwc(y1) - ref[:, Cup:]).abs().max().item() <= tol(dt, ref)
 
 
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 32, 128, 64, 64), (2, 48, 32, 0, 16), (1, 24, 64, 64, 32)], ids=["d2", "d4_c16", "d3"])
+def test_conv_dgrad_pool2(shape, dtn):
+    """decoder conv1 data gradient with the nearest-x2 upsample backward fused: the up part comes out 2x2-summed at
+    half resolution, the skip part at full resolution."""
+    dt = DT[dtn]
+    N, H, Cup, Cskip, K = shape
+    w = gen(K, Cup + Cskip, 3, 3, seed=231, scale=0.05)
+    dz = gen(N, K, H, H, seed=232)
+    xin = torch.zeros(N, Cup + Cskip, H, H, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, rnd(w, dt).double(), padding=1).backward(rnd(dz, dt).double())
+    ref = xin.grad.float()
+    ref_up = F.avg_pool2d(ref[:, :Cup], 2) * 4.0
+    dzd = to_nhwc(dz, dt)
+    wt = D(w.permute(1, 2, 3, 0).contiguous().to(dt))
+    y0 = torch.full((N, H // 2, H // 2, Cup), float("nan"), dtype=dt, device=dev())
+    y1 = torch.full((N, H, H, max(Cskip, 8)), float("nan"), dtype=dt, device=dev()) if Cskip else None
+    d = conv_desc(dt, N, H, H, H, H, Cup + Cskip, 3, 1, 1, 1, mk_src(dzd, K))
+    rc = vk.lib().vk_conv_dgrad_pool2(C.byref(d), wt.data_ptr(), y0.data_ptr(), y1.data_ptr() if Cskip else None, Cup if Cskip else 0, 0, st())
+    vk._lib.check(rc)
+    torch.cuda.synchronize()
+    t = tol(dt, ref_up) * (1.0 if dt == torch.float32 else 1.5)
+    assert (from_nhwc(y0) - ref_up).abs().max().item() <= t
+    if Cskip:
+        assert (from_nhwc(y1) - ref[:, Cup:]).abs().max().item() <= tol(dt, ref)
+
+
 # ------------------------------------------------------------------------------------------------ wgrad
 WGRAD_CASES = [
     ("l1", 2, 24, 64, 64, 3, 1, 1),

@@ -51,6 +51,7 @@ SIGNATURES = {
     "vk_prof_enable": (ci, [ci]),
     "vk_prof_collect": (ci, [C.c_char_p, sz]),
     "vk_conv_fwd": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp, vp]),
+    "vk_conv_dgrad_pool2": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp]),
     "vk_stem_fwd": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     "vk_conv_wgrad": (ci, [P(vk_conv_desc), vp, vp, vp, sz, vp]),
     "vk_stem_wgrad": (ci, [ci, ci, ci, ci, vp, vp, vp, vp]),

@@ -37,7 +37,7 @@ struct HaloParams {
   void* y1;
   int ld0, ld1, split;
   double* stats;
-  int N, H, W, K, C, flip, accumulate;
+  int N, H, W, K, C, flip, accumulate, pool2;
   int tiles_x, tiles_y, nchunks;
 };
 
@@ -70,6 +70,131 @@ struct HaloCfg {
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
+
+// ---- shared epilogue: accumulators -> LDS [tile pixel][channel] as T -> 16-byte NHWC stores
+//   * optional BN partial sums (sum / sum of squares of the stored values, fp64 atomics into replicated slabs)
+//   * optional channel split (concat gradient): channels >= split go to y1
+//   * optional pool2: the FIRST output part is summed over 2x2 pixel groups and written at half resolution
+//     (nearest-x2 upsample backward fused into the data gradient; the full-resolution tensor never exists)
+template <typename T, int TH, int BN, int TP, int TC>
+__device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP], const HaloParams& p, int n, int y0, int x0, int n0,
+                                              int wrow0, int wch0) {
+  using Tr = ElemTraits<T>;
+  constexpr int EB = Tr::kBytes, VE = Tr::kVec;
+  constexpr int BM = TH * 16;
+  constexpr int ESB = BN * EB + 16;
+  constexpr int EVPR = BN / VE, ERPP = 256 / EVPR, EPASS = BM / ERPP;
+  constexpr int RED_OFF = BM * ESB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+      const int ch = wch0 + a * 16 + kg * 4;
+      const int px = (wrow0 + b) * 16 + li;
+      char* dst = smem + px * ESB + ch * EB;
+      if (EB == 4) {
+        *reinterpret_cast<f32x4_t*>(dst) = acc[a][b];
+      } else {
+        float f[8] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3], 0.f, 0.f, 0.f, 0.f};
+        const u32x4_t pk = Vec16<T>::pack(f);
+        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pk[0], pk[1]};
+      }
+    }
+  __syncthreads();
+
+  const int e_row = tid / EVPR, e_vec = tid % EVPR;
+  const int col0 = n0 + e_vec * VE;
+  const bool col_ok = col0 < p.K;
+  char* yb = (char*)p.y0;
+  int ld = p.ld0, colx = col0;
+  bool first_part = true;
+  if (p.split > 0 && col0 >= p.split) { yb = (char*)p.y1; ld = p.ld1; colx = col0 - p.split; first_part = false; }
+  float s1[VE], s2[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (p.pool2 && first_part) {
+    // (TH/2) x 8 pooled pixels; tile origins are even, H and W are even
+    const int Hh = p.H >> 1, Wh = p.W >> 1;
+    for (int pr = e_row; pr < (TH / 2) * 8; pr += ERPP) {
+      const int py = pr >> 3, px = pr & 7;
+      const int y = (y0 >> 1) + py, x = (x0 >> 1) + px;
+      if (y < Hh && x < Wh && col_ok) {
+        float f[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) f[j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = (2 * py + (q >> 1)) * 16 + 2 * px + (q & 1);
+          float t[VE];
+          Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(smem + row * ESB + e_vec * 16), t);
+#pragma unroll
+          for (int j = 0; j < VE; ++j) f[j] += t[j];
+        }
+        u32x4_t* gp = reinterpret_cast<u32x4_t*>(yb + ((((size_t)n * Hh + y) * Wh + x) * ld + colx) * EB);
+        if (p.accumulate) {
+          float o[VE];
+          Vec16<T>::unpack(*gp, o);
+#pragma unroll
+          for (int j = 0; j < VE; ++j) f[j] += o[j];
+        }
+        *gp = Vec16<T>::pack(f);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ps = 0; ps < EPASS; ++ps) {
+      const int row = e_row + ps * ERPP;          // tile pixel index
+      const int y = y0 + (row >> 4), x = x0 + (row & 15);
+      if (y < p.H && x < p.W && col_ok) {
+        const size_t m = ((size_t)n * p.H + y) * p.W + x;
+        u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + row * ESB + e_vec * 16);
+        u32x4_t* gp = reinterpret_cast<u32x4_t*>(yb + (m * ld + colx) * EB);
+        float f[VE];
+        Vec16<T>::unpack(v, f);
+        if (p.accumulate) {
+          float o[VE];
+          Vec16<T>::unpack(*gp, o);
+#pragma unroll
+          for (int j = 0; j < VE; ++j) f[j] += o[j];
+          v = Vec16<T>::pack(f);
+          Vec16<T>::unpack(v, f);
+        }
+#pragma unroll
+        for (int j = 0; j < VE; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
+        *gp = v;
+      }
+    }
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+#pragma unroll
+      for (int o = EVPR; o < 64; o <<= 1) {
+        s1[j] += __shfl_xor(s1[j], o, 64);
+        s2[j] += __shfl_xor(s2[j], o, 64);
+      }
+    }
+    float* red = reinterpret_cast<float*>(smem + RED_OFF);
+    if (lane < EVPR) {
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        red[(wave * BN + lane * VE + j) * 2 + 0] = s1[j];
+        red[(wave * BN + lane * VE + j) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.K) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      double* sp = p.stats + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * p.K;
+      atomicAdd(sp + n0 + tid, (double)a);
+      atomicAdd(sp + p.K + n0 + tid, (double)b);
+    }
+  }
+}
 
 template <typename T, int TH, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p) {
@@ -249,85 +374,135 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
     if (st + 1 < nst) stage(st + 1, breg1, breg0);      // odd stage : reads B[1], stores set 0 -> B[0], loads set 1
   }
 
-  // ---- epilogue: accumulators -> LDS [tile pixel][channel] as T -> 16-byte NHWC stores (+ BN partial sums)
-  constexpr int ESB = Cfg::ESB;
+  halo_epilogue<T, TH, BN, TP, TC>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
+}
+
+// ---- C == 16 (16-bit types): decoder block 4 conv2 and the data gradients whose reduction runs over 16 channels.
+// A pixel is 32 bytes, so one K=32 MFMA step covers TWO taps x 16 channels; 9 taps = 5 steps (the 10th half reads zeros).
+// Everything (18x18 halo, all 9 taps of weights) is staged once: these layers are HBM-bound, the kernel is a
+// load -> 20..40 MFMAs -> store pipeline with 5 workgroups resident per CU.
+template <typename T, int BN>
+struct C16Cfg {
+  static constexpr int TH = 16, HPIX = 18 * 18;
+  static constexpr int APS = 48;                       // 32-byte pixel + 16 pad
+  static constexpr int A_BYTES = HPIX * APS + 64;      // + a zero line for the non-existent 10th tap
+  static constexpr int BS = 336;                       // weight row: 160 x 2 B + 16 pad
+  static constexpr int B_BYTES = BN * BS;
+  static constexpr int TP = 4, TC = BN / 16;
+  static constexpr int ESB = BN * 2 + 16;
+  static constexpr int EPI = 256 * ESB + 4 * BN * 2 * 4;
+  static constexpr int MAIN = A_BYTES + B_BYTES;
+  static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
+};
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const HaloParams p) {
+  using Cfg = C16Cfg<T, BN>;
+  constexpr int TH = 16, HPIX = Cfg::HPIX, APS = Cfg::APS, BS = Cfg::BS, TP = Cfg::TP, TC = Cfg::TC, VE = 8;
+  static_assert(sizeof(T) == 2, "C16 kernel is for 16-bit element types (fp32 uses the generic kernel with 16-channel chunks)");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Abuf = smem;
+  char* const Bbuf = smem + Cfg::A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bt = blockIdx.x;
+  const int tx = bt % p.tiles_x;
+  bt /= p.tiles_x;
+  const int ty = bt % p.tiles_y;
+  const int n = bt / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const int n0 = blockIdx.y * BN;
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.s0.ptr, p.s0.bytes);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
+
+  // ---- stage halo (2 vectors per pixel) with the BN+ReLU prologue, and all weights of this channel tile
+  const bool aff = p.s0.scale != nullptr, relu = p.s0.relu != 0;
+  const int hv = tid & 1;
+  float sc[VE], sh[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) {
+    sc[j] = aff ? p.s0.scale[hv * VE + j] : 1.f;
+    sh[j] = aff ? p.s0.shift[hv * VE + j] : 0.f;
+  }
+  constexpr int NPV = (HPIX * 2 + 255) / 256;
+  u32x4_t areg[NPV];
+  bool aok[NPV];
+#pragma unroll
+  for (int i = 0; i < NPV; ++i) {
+    const int hp = (tid >> 1) + i * 128;
+    const int hy = hp / 18, hx = hp - hy * 18;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    aok[i] = hp < HPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    const uint32_t off = (uint32_t)(((n * p.H + y) * p.W + x) * 16 + hv * VE) * 2u;
+    areg[i] = buf_load16(rs0, aok[i] ? off : kOOB);
+  }
+  constexpr int NBV = (BN * 18 + 255) / 256;          // 144 elements = 18 vectors per weight row
+  u32x4_t breg[NBV];
+#pragma unroll
+  for (int i = 0; i < NBV; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / 18, v = idx - row * 18;     // vector v = tap (v >> 1), channel half (v & 1)
+    const int tap = p.flip ? 8 - (v >> 1) : (v >> 1);
+    const bool ok = idx < BN * 18 && n0 + row < p.K;
+    breg[i] = buf_load16(rsw, ok ? (uint32_t)(((n0 + row) * 9 + tap) * 16 + (v & 1) * VE) * 2u : kOOB);
+  }
+  if (tid < 4) *reinterpret_cast<u32x4_t*>(Abuf + HPIX * APS + tid * 16) = u32x4_t{0, 0, 0, 0};
+  if (tid < BN) {     // zero the 16 padding elements (k = 144..159) of every weight row
+    *reinterpret_cast<u32x4_t*>(Bbuf + tid * BS + 288) = u32x4_t{0, 0, 0, 0};
+    *reinterpret_cast<u32x4_t*>(Bbuf + tid * BS + 304) = u32x4_t{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int i = 0; i < NPV; ++i) {
+    const int hp = (tid >> 1) + i * 128;
+    if (hp >= HPIX) continue;
+    u32x4_t v = areg[i];
+    if (aff) {
+      float f[VE];
+      Vec16<T>::unpack(v, f);
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        f[j] = fmaf(f[j], sc[j], sh[j]);
+        if (relu) f[j] = fmaxf(f[j], 0.f);
+      }
+      v = Vec16<T>::pack(f);
+      if (!aok[i]) v = u32x4_t{0, 0, 0, 0};
+    }
+    *reinterpret_cast<u32x4_t*>(Abuf + hp * APS + hv * 16) = v;
+  }
+#pragma unroll
+  for (int i = 0; i < NBV; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < BN * 18) *reinterpret_cast<u32x4_t*>(Bbuf + (idx / 18) * BS + (idx % 18) * 16) = breg[i];
+  }
+  __syncthreads();
+
+  // ---- 5 MFMA steps: lane (li, kg) covers tap 2*step + (kg >> 1), channels 8*(kg & 1)..+7
+  const int wrow0 = wave * 4;
+  const int li = lane & 15, kg = lane >> 4;
+  f32x4_t acc[TC][TP];
 #pragma unroll
   for (int a = 0; a < TC; ++a)
 #pragma unroll
-    for (int b = 0; b < TP; ++b) {
-      const int ch = wch0 + a * 16 + kg * 4;
-      const int px = (wrow0 + b) * 16 + li;
-      char* dst = smem + px * ESB + ch * EB;
-      if (EB == 4) {
-        *reinterpret_cast<f32x4_t*>(dst) = acc[a][b];
-      } else {
-        float f[8] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3], 0.f, 0.f, 0.f, 0.f};
-        const u32x4_t pk = Vec16<T>::pack(f);
-        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pk[0], pk[1]};
-      }
-    }
+    for (int b = 0; b < TP; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int step = 0; step < 5; ++step) {
+    const int tap = 2 * step + (kg >> 1);
+    const int r = tap / 3, s = tap - r * 3;
+    const bool zero = tap >= 9;
+    // per-lane base of this step's A reads (the zero line when the tap does not exist)
+    const int abase = zero ? HPIX * APS : ((wrow0 + r) * 18 + li + s) * APS + (kg & 1) * 16;
+    const int astep = zero ? 0 : 18 * APS;
+    u32x4_t wf[TC], xf[TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(Bbuf + (a * 16 + li) * BS + step * 64 + kg * 16);
+#pragma unroll
+    for (int b = 0; b < TP; ++b) xf[b] = *reinterpret_cast<const u32x4_t*>(Abuf + abase + b * astep);
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) acc[a][b] = Mma<T>::run(wf[a], xf[b], acc[a][b]);
+  }
   __syncthreads();
-
-  constexpr int EVPR = Cfg::EVPR, ERPP = Cfg::ERPP, EPASS = Cfg::EPASS;
-  const int e_row = tid / EVPR, e_vec = tid % EVPR;
-  const int col0 = n0 + e_vec * VE;
-  const bool col_ok = col0 < p.K;
-  char* yb = (char*)p.y0;
-  int ld = p.ld0, colx = col0;
-  if (p.split > 0 && col0 >= p.split) { yb = (char*)p.y1; ld = p.ld1; colx = col0 - p.split; }
-  float s1[VE], s2[VE];
-#pragma unroll
-  for (int j = 0; j < VE; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-#pragma unroll
-  for (int ps = 0; ps < EPASS; ++ps) {
-    const int row = e_row + ps * ERPP;          // tile pixel index
-    const int y = y0 + (row >> 4), x = x0 + (row & 15);
-    if (y < p.H && x < p.W && col_ok) {
-      const size_t m = ((size_t)n * p.H + y) * p.W + x;
-      u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + row * ESB + e_vec * 16);
-      u32x4_t* gp = reinterpret_cast<u32x4_t*>(yb + (m * ld + colx) * EB);
-      float f[VE];
-      Vec16<T>::unpack(v, f);
-      if (p.accumulate) {
-        float o[VE];
-        Vec16<T>::unpack(*gp, o);
-#pragma unroll
-        for (int j = 0; j < VE; ++j) f[j] += o[j];
-        v = Vec16<T>::pack(f);
-        Vec16<T>::unpack(v, f);
-      }
-#pragma unroll
-      for (int j = 0; j < VE; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
-      *gp = v;
-    }
-  }
-  if (p.stats) {
-#pragma unroll
-    for (int j = 0; j < VE; ++j) {
-#pragma unroll
-      for (int o = EVPR; o < 64; o <<= 1) {
-        s1[j] += __shfl_xor(s1[j], o, 64);
-        s2[j] += __shfl_xor(s2[j], o, 64);
-      }
-    }
-    float* red = reinterpret_cast<float*>(smem + Cfg::RED_OFF);
-    if (lane < EVPR) {
-#pragma unroll
-      for (int j = 0; j < VE; ++j) {
-        red[(wave * BN + lane * VE + j) * 2 + 0] = s1[j];
-        red[(wave * BN + lane * VE + j) * 2 + 1] = s2[j];
-      }
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.K) {
-      float a = 0.f, b = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
-      double* sp = p.stats + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * p.K;
-      atomicAdd(sp + n0 + tid, (double)a);
-      atomicAdd(sp + p.K + n0 + tid, (double)b);
-    }
-  }
+  halo_epilogue<T, TH, BN, TP, TC>(smem, acc, p, n, y0, x0, n0, wrow0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -373,14 +548,35 @@ static int halo_select(const HaloParams& p, hipStream_t st) {
   return launch_halo<T, 16, 16, 4, 1>(p, st);
 }
 
+template <typename T, int BN>
+static int launch_c16(HaloParams p, hipStream_t st) {
+  using Cfg = C16Cfg<T, BN>;
+  p.tiles_x = (p.W + 15) / 16;
+  p.tiles_y = (p.H + 15) / 16;
+  dim3 grid((unsigned)(p.N * p.tiles_y * p.tiles_x), (unsigned)((p.K + BN - 1) / BN), 1);
+  {
+    static const std::string tag_f = std::string("c16_16b_bn") + std::to_string(BN);
+    static const std::string tag_d = tag_f + "_dgrad";
+    const std::string& btag = p.flip ? tag_d : tag_f;
+    const double bytes = ((double)p.N * p.H * p.W * (16.0 + p.K * (p.pool2 ? 0.25 : 1.0)) + 9.0 * p.K * 16.0) * 2.0;
+    vkh::ProfScope ps(btag.c_str(), st, 2.0 * (double)p.N * p.H * p.W * p.K * 144.0, bytes);
+    hipLaunchKernelGGL((conv3x3_c16_kernel<T, BN>), grid, dim3(256), Cfg::SMEM, st, p);
+  }
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
 // returns VK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the tap-by-tap kernel)
 int conv3x3_halo_try(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate, double* stats,
-                     hipStream_t st) {
+                     int pool2, hipStream_t st) {
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->H != d->Ho || d->W != d->Wo) return VK_ERR_UNSUPPORTED;
   const int eb = d->dtype == VK_F32 ? 4 : 2;
   const int ck = 64 / eb;
   const int C = d->src0.C + (d->src1.ptr ? d->src1.C : 0);
-  if (d->src0.C % ck || (d->src1.ptr && d->src1.C % ck) || d->K % 16) return VK_ERR_UNSUPPORTED;
+  const bool c16 = (eb == 2) && C == 16 && !d->src1.ptr && !d->src0.up;
+  if (!c16 && (d->src0.C % ck || (d->src1.ptr && d->src1.C % ck))) return VK_ERR_UNSUPPORTED;
+  if (d->K % 16) return VK_ERR_UNSUPPORTED;
+  if (pool2 && ((d->H | d->W) & 1)) return VK_ERR_UNSUPPORTED;
   if (d->src1.ptr && d->src1.up) return VK_ERR_UNSUPPORTED;
   if ((size_t)d->N * d->H * d->W * C * eb >= (1ull << 31) || (size_t)d->N * d->H * d->W >= (1ull << 31)) return VK_ERR_UNSUPPORTED;
   HaloParams p;
@@ -402,7 +598,12 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, void* y, void* y1, in
   p.N = d->N; p.H = d->H; p.W = d->W; p.K = d->K; p.C = C;
   p.flip = d->transposed;
   p.accumulate = accumulate;
-  p.nchunks = C / ck;
+  p.pool2 = pool2;
+  p.nchunks = c16 ? 1 : C / ck;
+  if (c16) {
+    if (d->dtype == VK_BF16) return d->K >= 32 ? launch_c16<bf16_t, 32>(p, st) : launch_c16<bf16_t, 16>(p, st);
+    return d->K >= 32 ? launch_c16<f16_t, 32>(p, st) : launch_c16<f16_t, 16>(p, st);
+  }
   p.tiles_x = p.tiles_y = 0;
   switch (d->dtype) {
     case VK_F32: return halo_select<float>(p, st);

@@ -797,6 +797,20 @@ int backward_decoder(vk_unet* h, int i, hipStream_t st) {
   // conv1 unit
   RET_IF(bn_relu_bwd_inplace(h, c1, st));
   RET_IF(conv_wgrad(h, c1, to_src(xprev, 1), d.Cskip ? to_src(skip) : null_src(), st));
+  // data gradient with the nearest-x2 upsample backward fused into its epilogue (the full-resolution d_up never exists);
+  // shapes the tile kernels do not cover fall back to dgrad + a separate 2x2-sum pass
+  {
+    vk_conv_desc dd;
+    dd.dtype = h->cfg.dtype;
+    dd.N = N; dd.H = c1.Hout; dd.W = c1.Hout; dd.Ho = c1.Hin; dd.Wo = c1.Hin;
+    dd.K = c1.Cin; dd.R = c1.R; dd.S = c1.R; dd.stride = 1; dd.pad = c1.pad; dd.transposed = 1;
+    vk_src s;
+    s.ptr = c1.g; s.C = c1.K; s.up = 0; s.scale = nullptr; s.shift = nullptr; s.relu = 0;
+    dd.src0 = s;
+    dd.src1 = null_src();
+    const int rc = vk_conv_dgrad_pool2(&dd, dgrad_weights(h, c1), g_prev, d.Cskip ? g_skip : nullptr, d.Cskip ? d.Cup : 0, 0, st);
+    if (rc != VK_ERR_UNSUPPORTED) return rc;
+  }
   void* dup = h->ws + h->off_dup;
   if (d.Cskip) RET_IF(conv_dgrad(h, c1, dup, g_skip, d.Cup, 0, st));
   else RET_IF(conv_dgrad(h, c1, dup, nullptr, 0, 0, st));
