@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--prof", action="store_true")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
     dev = torch.device("cuda:0")
@@ -76,6 +77,14 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.reps
+            if a.prof:
+                lib.vk_prof_enable(1)
+                for _ in range(5):
+                    f()
+                torch.cuda.synchronize()
+                lib.vk_prof_enable(0)
+                for k, v in L_.prof_collect().items():
+                    print(f"        {k:40s} {v['ms'] / v['n'] * 1e3:9.1f} us/launch")
             print(f"{name:5s} {op:6s} H{H:<4d} C{Ctot:<4d} K{K:<4d} {us:9.1f} us  {flops / us / 1e6:8.1f} TF  ({flops / us / 1e6 / 2500 * 100:5.1f} % of MFMA peak)", flush=True)
 
 

@@ -288,26 +288,30 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
   // stage the fp32 output tile [k][tap][c] in LDS (WS: the four waves add their partial tiles with LDS atomics),
   // then write whole 16-byte vectors: plain stores into this split's slab, or fp32 atomics when no slab was given
   float* red = reinterpret_cast<float*>(smem);
-  if (WS) {
-    for (int i = tid; i < KT * CT * 9; i += NT) red[i] = 0.f;
+  // WS: the four waves hold partial sums of the SAME output tile (identical lane -> element mapping): they add
+  // themselves into the LDS tile one after the other (ds_add_f32 atomics proved ~10x slower than this).
+#pragma unroll 1
+  for (int phase = 0; phase < (WS ? 4 : 1); ++phase) {
+    if (!WS || wave == phase) {
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        const int tp = (TS && half) ? 5 + t : t;
+        if (tp >= 9) continue;
+#pragma unroll
+        for (int a = 0; a < TK; ++a)
+#pragma unroll
+          for (int b = 0; b < TCc; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = wk0 + a * 16 + (lane >> 4) * 4 + e, c = wc0 + b * 16 + (lane & 15);
+              float* dst = red + (k * 9 + tp) * CT + c;
+              if (WS && phase > 0) *dst += acc[t][a][b][e];
+              else *dst = acc[t][a][b][e];
+            }
+      }
+    }
     __syncthreads();
   }
-#pragma unroll
-  for (int t = 0; t < NTAP; ++t) {
-    const int tp = (TS && half) ? 5 + t : t;
-    if (tp >= 9) continue;
-#pragma unroll
-    for (int a = 0; a < TK; ++a)
-#pragma unroll
-      for (int b = 0; b < TCc; ++b)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = wk0 + a * 16 + (lane >> 4) * 4 + e, c = wc0 + b * 16 + (lane & 15);
-          if (WS) atomicAdd(red + (k * 9 + tp) * CT + c, acc[t][a][b][e]);
-          else red[(k * 9 + tp) * CT + c] = acc[t][a][b][e];
-        }
-  }
-  __syncthreads();
   constexpr int C4 = CT / 4;
   float* const slab = p.slab ? p.slab + (size_t)blockIdx.z * p.K * 9 * p.C : nullptr;
   for (int i = tid; i < KT * 9 * C4; i += NT) {
@@ -368,7 +372,7 @@ static int launch_wh(WhParams p, size_t slab_bytes, hipStream_t st) {
   if (kt * ct > wh_max_combo()) return VK_ERR_UNSUPPORTED;      // deep layers: output tile traffic would dominate
   // every workgroup ends with KT*CT*9 fp32 atomics: give it at least ~6 pixel tiles of work
   const char* e_blk = getenv("VK_WH_BLOCKS");
-  const int target_blocks = e_blk ? atoi(e_blk) : (WS ? 1024 : 256);       // non-WS: LDS allows exactly one workgroup per CU
+  const int target_blocks = e_blk ? atoi(e_blk) : (WS ? (KT >= 32 ? 512 : 1024) : 256);       // non-WS: LDS allows exactly one workgroup per CU
   int splits = target_blocks / (kt * ct);     // never exceed the target: a second round of workgroups costs a full round
   if (splits > p.ntiles / 6) splits = p.ntiles / 6;
   if (splits < 1) splits = 1;
@@ -389,10 +393,11 @@ static int launch_wh(WhParams p, size_t slab_bytes, hipStream_t st) {
     const std::string dtag = getenv("VK_PROF_DETAIL") ? tag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) + "_s" + std::to_string(splits) : tag;
     vkh::ProfScope ps(dtag.c_str(), st, 2.0 * (double)p.N * p.H * p.W * p.K * 9.0 * p.C, bytes);
     hipLaunchKernelGGL((wgrad_halo_kernel<T, KT, CT, WS, TS>), grid, dim3(Cfg::NT), Cfg::SMEM, st, p);
-    if (p.slab) {
-      const size_t n4 = (size_t)p.K * 9 * p.C / 4;
-      hipLaunchKernelGGL(k_wgrad_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, n4, splits, p.slab, p.dw);
-    }
+  }
+  if (p.slab) {
+    const size_t n4 = (size_t)p.K * 9 * p.C / 4;
+    vkh::ProfScope ps("wgrad_slab_reduce", st, 0.0, (double)(splits + 2) * n4 * 16.0);
+    hipLaunchKernelGGL(k_wgrad_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, n4, splits, p.slab, p.dw);
   }
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
@@ -406,6 +411,9 @@ static int wh_select(const WhParams& p, int cgran, size_t slab_bytes, hipStream_
       if (getenv("VK_WH_NO_TS")) return launch_wh<T, 64, 64, false>(p, slab_bytes, st);
       return launch_wh<T, 64, 64, false, true>(p, slab_bytes, st);
     }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (p.K >= 32 && cgran % 64 == 0) return launch_wh<T, 32, 64, false, true>(p, slab_bytes, st);   // decoder block 3 conv1
   }
   if (p.K >= 32 && cgran % 32 == 0) return launch_wh<T, 32, 32, true>(p, slab_bytes, st);
   if (p.K >= 16 && cgran % 32 == 0) return launch_wh<T, 16, 32, true>(p, slab_bytes, st);
