@@ -148,6 +148,16 @@ def main():
                 roof = {"kernel": tag, "bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM, 4), "traffic": None, "launches_per_step": r["n"] / args.prof_steps,
                         "avg_launch_ms": round(per_launch_ms, 4)}
+            # HBM traffic of the dominant kernel: offline rocprofv3 PMC measurement committed under profiles/ (bench.py itself
+            # cannot run the profiler); null when that kernel family was not measured
+            try:
+                tj = json.load(open(ROOT / "profiles" / "r01" / "traffic.json"))
+                if tag in tj:
+                    roof["traffic"] = round(tj[tag]["fetch_bytes"] + tj[tag]["write_bytes"])
+                    roof["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch, FETCH doubled for gfx950)"
+                    roof["algorithmic_bytes_per_launch"] = round(r["bytes"] / r["n"])
+            except Exception:
+                pass
             tot = sum(v["ms"] for v in table.values())
             roof["share_of_gpu_time"] = round(r["ms"] / tot, 3)
             roof["all_kernels_ms_per_step"] = {k: round(v["ms"] / args.prof_steps, 3) for k, v in

@@ -331,18 +331,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
   auto compute = [&](int bbuf, int r) {
     const char* A = a_lane + r * (18 * APS);
     const char* B = Bbuf + bbuf * Cfg::B_BYTES + b_lane;
+    // fragments of tap s+1 are read before the MFMAs of tap s are issued (explicit one-tap software pipeline)
+    u32x4_t wf[2][TC], xf[2][TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a) wf[0][a] = *reinterpret_cast<const u32x4_t*>(B + (a * 16) * 64);
+#pragma unroll
+    for (int b = 0; b < TP; ++b) xf[0][b] = *reinterpret_cast<const u32x4_t*>(A + (b * 18) * APS);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      u32x4_t wf[TC], xf[TP];
+      if (s < 2) {
 #pragma unroll
-      for (int a = 0; a < TC; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(B + (s * BN + a * 16) * 64);
+        for (int a = 0; a < TC; ++a) wf[(s + 1) & 1][a] = *reinterpret_cast<const u32x4_t*>(B + ((s + 1) * BN + a * 16) * 64);
 #pragma unroll
-      for (int b = 0; b < TP; ++b) xf[b] = *reinterpret_cast<const u32x4_t*>(A + (b * 18 + s) * APS);
+        for (int b = 0; b < TP; ++b) xf[(s + 1) & 1][b] = *reinterpret_cast<const u32x4_t*>(A + (b * 18 + s + 1) * APS);
+      }
 #pragma unroll
       for (int a = 0; a < TC; ++a)
 #pragma unroll
-        for (int b = 0; b < TP; ++b) acc[a][b] = Mma<T>::run(wf[a], xf[b], acc[a][b]);
+        for (int b = 0; b < TP; ++b) acc[a][b] = Mma<T>::run(wf[s & 1][a], xf[s & 1][b], acc[a][b]);
     }
+    // pin the issue order: [reads tap0][reads tap1][MFMAs tap0][reads tap2][MFMAs tap1][MFMAs tap2]
+    constexpr int NR = TC + TP, NM = TC * TP * (sizeof(T) == 4 ? 4 : 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
   };
 
   // ---- pipeline over (chunk, filter row) stages.  Halo: single LDS buffer, next chunk waits in registers for three
