@@ -134,7 +134,14 @@ def main():
         table = vk._lib.prof_collect()
         _log("event profile collected")
         if table:
-            dom = max(table.items(), key=lambda kv: kv[1]["ms"])
+            # group like rocprofv3 does (by kernel symbol): forward and data-gradient launches of one kernel share a family
+            fam = {}
+            for k, v in table.items():
+                b = k[:-6] if k.endswith("_dgrad") else k
+                f = fam.setdefault(b, dict(n=0, ms=0.0, flops=0.0, bytes=0.0))
+                for q in ("n", "ms", "flops", "bytes"):
+                    f[q] += v[q]
+            dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
             tag, r = dom
             per_launch_ms = r["ms"] / r["n"]
             if r["flops"] > 0 and any(k in tag for k in ("igemm", "wgrad", "stem", "halo")):
