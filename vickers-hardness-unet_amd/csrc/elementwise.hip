@@ -464,100 +464,152 @@ __device__ __forceinline__ void load_act16(const T* p, const float* sc, const fl
   }
 }
 
+// ---- forward: 16x16 pixel tile per workgroup; the 18x18x16 activated halo (BN + ReLU applied ONCE per element) is
+// staged in LDS as fp32 (80-byte pixel stride: conflict-free ds_read_b128); weights are read through a uniform
+// pointer with compile-time indices, i.e. they live in scalar registers.
 template <typename T>
-__global__ __launch_bounds__(256) void k_head_fwd(int N, int H, int W, const T* __restrict__ z, const float* __restrict__ scale,
-                                                  const float* __restrict__ shift, int relu, const float* __restrict__ w,
-                                                  const float* __restrict__ bias, float* __restrict__ logits) {
-  __shared__ float ws[144], scs[16], shs[16];
+__global__ __launch_bounds__(256) void k_head_fwd(int N, int H, int W, int tiles_x, int tiles_y, const T* __restrict__ z,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                  const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ logits) {
+  constexpr int VE = ElemTraits<T>::kVec, VPP = 16 / VE;      // vectors per pixel
+  constexpr int PS = 20;                                      // floats per LDS pixel (16 + 4 pad)
+  __shared__ __attribute__((aligned(16))) float tile[18 * 18 * PS];
+  const int tid = threadIdx.x;
+  int bt = blockIdx.x;
+  const int tx0 = bt % tiles_x;
+  bt /= tiles_x;
+  const int ty0 = bt % tiles_y;
+  const int n = bt / tiles_y;
+  const int y0 = ty0 * 16, x0 = tx0 * 16;
   const bool affine = scale != nullptr;
-  if (threadIdx.x < 144) ws[threadIdx.x] = w[threadIdx.x];
-  if (threadIdx.x < 16) {
-    scs[threadIdx.x] = affine ? scale[threadIdx.x] : 1.f;
-    shs[threadIdx.x] = affine ? shift[threadIdx.x] : 0.f;
-  }
-  __syncthreads();
-  float sc[16], sh[16];
+  for (int v = tid; v < 324 * VPP; v += 256) {
+    const int hp = v / VPP, vec = v % VPP;
+    const int hy = hp / 18, hx = hp - hy * 18;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    float f[VE];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { sc[j] = scs[j]; sh[j] = shs[j]; }
-  const float b0 = bias[0];
-  const size_t total = (size_t)N * H * W;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int wq = (int)(i % W);
-    const size_t t = i / W;
-    const int hq = (int)(t % H);
-    const size_t n = t / H;
-    float acc = b0;
+    for (int j = 0; j < VE; ++j) f[j] = 0.f;
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+      Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(z + (((size_t)n * H + y) * W + x) * 16 + vec * VE), f);
+      if (affine) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int hh = hq + r - 1;
-      if ((unsigned)hh >= (unsigned)H) continue;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int ww = wq + s - 1;
-        if ((unsigned)ww >= (unsigned)W) continue;
-        float a[16];
-        load_act16<T>(z + ((n * H + hh) * W + ww) * 16, sc, sh, affine, relu != 0, a);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc = fmaf(a[j], ws[(r * 3 + s) * 16 + j], acc);
+        for (int j = 0; j < VE; ++j) {
+          f[j] = fmaf(f[j], scale[vec * VE + j], shift[vec * VE + j]);
+          if (relu) f[j] = fmaxf(f[j], 0.f);
+        }
       }
     }
-    logits[i] = acc;
+#pragma unroll
+    for (int j = 0; j < VE; j += 4) *reinterpret_cast<f32x4_t*>(&tile[hp * PS + vec * VE + j]) = f32x4_t{f[j], f[j + 1], f[j + 2], f[j + 3]};
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  float acc = bias[0];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const float* a = &tile[((ty + r) * 18 + tx + s) * PS];
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) {
+        const f32x4_t av = *reinterpret_cast<const f32x4_t*>(a + j);
+        acc = fmaf(av[0], w[(r * 3 + s) * 16 + j], acc);
+        acc = fmaf(av[1], w[(r * 3 + s) * 16 + j + 1], acc);
+        acc = fmaf(av[2], w[(r * 3 + s) * 16 + j + 2], acc);
+        acc = fmaf(av[3], w[(r * 3 + s) * 16 + j + 3], acc);
+      }
+    }
+  const int y = y0 + ty, x = x0 + tx;
+  if (y < H && x < W) logits[((size_t)n * H + y) * W + x] = acc;
+}
+
+// ---- backward, data: dy[m][c] = sum_tap dl[m + (1-r, 1-s)] * w[tap][c]
+template <typename T>
+__global__ __launch_bounds__(256) void k_head_dgrad(int N, int H, int W, int tiles_x, int tiles_y, const float* __restrict__ w,
+                                                    const float* __restrict__ dl, T* __restrict__ dy) {
+  constexpr int VE = ElemTraits<T>::kVec;
+  __shared__ float dt[18 * 18];
+  const int tid = threadIdx.x;
+  int bt = blockIdx.x;
+  const int tx0 = bt % tiles_x;
+  bt /= tiles_x;
+  const int ty0 = bt % tiles_y;
+  const int n = bt / tiles_y;
+  const int y0 = ty0 * 16, x0 = tx0 * 16;
+  for (int hp = tid; hp < 324; hp += 256) {
+    const int hy = hp / 18, hx = hp - hy * 18;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    dt[hp] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? dl[((size_t)n * H + y) * W + x] : 0.f;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  float o[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) o[j] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const float d = dt[(ty + 2 - r) * 18 + tx + 2 - s];      // halo origin is (y0-1, x0-1): pixel + (1 - r, 1 - s)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] = fmaf(d, w[(r * 3 + s) * 16 + j], o[j]);
+    }
+  const int y = y0 + ty, x = x0 + tx;
+  if (y < H && x < W) {
+    T* dst = dy + (((size_t)n * H + y) * W + x) * 16;
+#pragma unroll
+    for (int v = 0; v < 16 / VE; ++v) *reinterpret_cast<u32x4_t*>(dst + v * VE) = Vec16<T>::pack(o + v * VE);
   }
 }
 
-// head backward: dy[m][c] = sum_tap dl[m + (1-r, 1-s)] * w[tap][c];   dw[tap][c] += dl[m + (1-r,1-s)] * a[m][c];  db += dl[m]
+// ---- backward, weights: dw[tap][c] += sum_m dl[m + (1-r, 1-s)] * a[m][c];  dbias += sum_m dl[m]
+// persistent workgroups walk 16x16 tiles; 144 + 1 accumulators per thread, one cross-lane reduction at the end.
 template <typename T>
-__global__ __launch_bounds__(256) void k_head_bwd(int N, int H, int W, const T* __restrict__ z, const float* __restrict__ scale,
-                                                  const float* __restrict__ shift, int relu, const float* __restrict__ w,
-                                                  const float* __restrict__ dl, T* __restrict__ dy, float* dw, float* dbias) {
-  __shared__ float ws[144], scs[16], shs[16];
+__global__ __launch_bounds__(256) void k_head_wgrad(int N, int H, int W, int tiles_x, int tiles_y, int ntiles, const T* __restrict__ z,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                    const float* __restrict__ dl, float* dw, float* dbias) {
+  __shared__ float dt[2][18 * 18];
   __shared__ float red[4][145];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   const bool affine = scale != nullptr;
-  if (threadIdx.x < 144) ws[threadIdx.x] = w[threadIdx.x];
-  if (threadIdx.x < 16) {
-    scs[threadIdx.x] = affine ? scale[threadIdx.x] : 1.f;
-    shs[threadIdx.x] = affine ? shift[threadIdx.x] : 0.f;
-  }
-  __syncthreads();
   float sc[16], sh[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { sc[j] = scs[j]; sh[j] = shs[j]; }
+  for (int j = 0; j < 16; ++j) { sc[j] = affine ? scale[j] : 1.f; sh[j] = affine ? shift[j] : 0.f; }
   float gw[144];
 #pragma unroll
   for (int j = 0; j < 144; ++j) gw[j] = 0.f;
   float gb = 0.f;
-  const size_t total = (size_t)N * H * W;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int wq = (int)(i % W);
-    const size_t t = i / W;
-    const int hq = (int)(t % H);
-    const size_t n = t / H;
-    float a[16], o[16];
-    load_act16<T>(z + i * 16, sc, sh, affine, relu != 0, a);
+  int it = 0;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
+    int bt = t;
+    const int tx0 = bt % tiles_x;
+    bt /= tiles_x;
+    const int ty0 = bt % tiles_y;
+    const int n = bt / tiles_y;
+    const int y0 = ty0 * 16, x0 = tx0 * 16;
+    float* d = dt[it & 1];
+    for (int hp = tid; hp < 324; hp += 256) {
+      const int hy = hp / 18, hx = hp - hy * 18;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      d[hp] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? dl[((size_t)n * H + y) * W + x] : 0.f;
+    }
+    const int y = y0 + ty, x = x0 + tx;
+    float a[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) o[j] = 0.f;
-    gb += dl[i];
+    for (int j = 0; j < 16; ++j) a[j] = 0.f;
+    if (y < H && x < W) load_act16<T>(z + (((size_t)n * H + y) * W + x) * 16, sc, sh, affine, relu != 0, a);
+    __syncthreads();                 // dl tile ready (the other buffer is free: it was last read two iterations ago)
+    gb += d[(ty + 1) * 18 + tx + 1];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int hh = hq + 1 - r;
-      if ((unsigned)hh >= (unsigned)H) continue;
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        const int ww = wq + 1 - s;
-        if ((unsigned)ww >= (unsigned)W) continue;
-        const float d = dl[(n * H + hh) * W + ww];
+        const float dv = d[(ty + 2 - r) * 18 + tx + 2 - s];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          o[j] = fmaf(d, ws[(r * 3 + s) * 16 + j], o[j]);
-          gw[(r * 3 + s) * 16 + j] = fmaf(d, a[j], gw[(r * 3 + s) * 16 + j]);
-        }
+        for (int j = 0; j < 16; ++j) gw[(r * 3 + s) * 16 + j] = fmaf(dv, a[j], gw[(r * 3 + s) * 16 + j]);
       }
-    }
-    constexpr int VE = ElemTraits<T>::kVec;
-#pragma unroll
-    for (int v = 0; v < 16 / VE; ++v) *reinterpret_cast<u32x4_t*>(dy + i * 16 + v * VE) = Vec16<T>::pack(o + v * VE);
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int j = 0; j < 144; ++j) {
     const float v = wave_sum(gw[j]);
@@ -568,9 +620,9 @@ __global__ __launch_bounds__(256) void k_head_bwd(int N, int H, int W, const T* 
     if (lane == 0) red[wave][144] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 145) {
-    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (threadIdx.x < 144) atomicAdd(dw + threadIdx.x, v);
+  if (tid < 145) {
+    const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < 144) atomicAdd(dw + tid, v);
     else atomicAdd(dbias, v);
   }
 }
@@ -831,7 +883,8 @@ extern "C" int vk_head_fwd(vk_dtype dtype, int N, int H, int W, const vk_src* sr
   VK_CHECK_ARG(src->C == 16 && !src->up, "vk_head_fwd: head input must have 16 channels, no upsample");
   hipStream_t st = (hipStream_t)stream;
   vkh::ProfScope ps_("head_fwd", st, 2.0 * 144.0 * N * H * W, (double)N * H * W * (16.0 * (dtype == VK_F32 ? 4.0 : 2.0) + 4.0));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_fwd<T>, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, st, N, H, W, (const T*)src->ptr,
+  const int tx = (W + 15) / 16, ty = (H + 15) / 16;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_fwd<T>, dim3((unsigned)(N * tx * ty)), dim3(256), 0, st, N, H, W, tx, ty, (const T*)src->ptr,
                                        src->scale, src->shift, src->relu, w9x16, bias, logits));
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
@@ -842,9 +895,19 @@ extern "C" int vk_head_bwd(vk_dtype dtype, int N, int H, int W, const vk_src* sr
   VK_CHECK_ARG(src && src->ptr && w9x16 && dlogits && dy && dw9x16 && dbias, "vk_head_bwd: null argument");
   VK_CHECK_ARG(src->C == 16 && !src->up, "vk_head_bwd: head input must have 16 channels, no upsample");
   hipStream_t st = (hipStream_t)stream;
-  vkh::ProfScope ps_("head_bwd", st, 4.0 * 144.0 * N * H * W, (double)N * H * W * (32.0 * (dtype == VK_F32 ? 4.0 : 2.0) + 4.0));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_bwd<T>, dim3(grid_for((size_t)N * H * W, 256, 1024)), dim3(256), 0, st, N, H, W,
-                                       (const T*)src->ptr, src->scale, src->shift, src->relu, w9x16, dlogits, (T*)dy, dw9x16, dbias));
+  const int tx = (W + 15) / 16, ty = (H + 15) / 16;
+  const int ntiles = N * tx * ty;
+  const double eb = dtype == VK_F32 ? 4.0 : 2.0;
+  {
+    vkh::ProfScope ps_("head_dgrad", st, 2.0 * 144.0 * N * H * W, (double)N * H * W * (16.0 * eb + 4.0));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_dgrad<T>, dim3((unsigned)ntiles), dim3(256), 0, st, N, H, W, tx, ty, w9x16, dlogits, (T*)dy));
+  }
+  {
+    vkh::ProfScope ps_("head_wgrad", st, 2.0 * 144.0 * N * H * W, (double)N * H * W * (16.0 * eb + 4.0));
+    const int nb = ntiles < 1024 ? ntiles : 1024;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_wgrad<T>, dim3((unsigned)nb), dim3(256), 0, st, N, H, W, tx, ty, ntiles, (const T*)src->ptr,
+                                         src->scale, src->shift, src->relu, dlogits, dw9x16, dbias));
+  }
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }
