@@ -99,6 +99,21 @@ int vk_conv_fwd(const vk_conv_desc* d, const void* w, void* y, void* y1, int spl
 int vk_conv_dgrad_pool2(const vk_conv_desc* d, const void* w, void* y_half, void* y1, int split_k1, int accumulate,
                         void* stream);
 
+/* BatchNorm+ReLU backward reduce fused into the kernel that produces the gradient: with y the gradient w.r.t. the
+ * activated tensor relu(z*scale+shift), the kernel stores g = y * [z*scale+shift > 0] instead of y and adds sum(g),
+ * sum(g*z) into sums [VK_STATS_REPLICAS][2][C] (caller zeroes).  Phase 2 is vk_bn_bwd_apply_fused with mask_mode 0. */
+typedef struct {
+  const void* z;        /* raw conv output the gradient belongs to, same shape as the gradient */
+  const float* scale;
+  const float* shift;
+  double* sums;
+} vk_bnr;
+
+/* Data gradient with optional fusions on the first output part (channels [0, split_k1), or all of them):
+ * pool2 (see vk_conv_dgrad_pool2) and/or bnr.  VK_ERR_UNSUPPORTED outside the 3x3 stride-1 tile kernels. */
+int vk_conv_dgrad_fused(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int pool2, const vk_bnr* bnr,
+                        void* stream);
+
 /* Stem: 7x7 stride-2 pad-3 convolution of x4 [N][H][W][4] (channel 3 is zero padding) with packed
  * weights wp [64][7][32] (tap row r, 8 columns x 4 channels, zero padded). */
 int vk_stem_fwd(vk_dtype dtype, int N, int H, int W, const void* x4, const void* wp, void* y, double* stats,
@@ -133,7 +148,7 @@ int vk_bn_add_relu(vk_dtype dtype, size_t pixels, int C, const void* z, const fl
                    const void* res, const float* rscale, const float* rshift, void* out, void* stream);
 
 /* BatchNorm(+ReLU) backward, two phases.  mask_mode 0: none, 1: relu(z*scale+shift) > 0, 2: mask_src > 0.
- * phase 1: sums double[2][C] += { sum g, sum g*z },  g = dy * mask.
+ * phase 1: sums double[VK_STATS_REPLICAS][2][C] += { sum g, sum g*z } (spread over the replicas),  g = dy * mask.
  * phase 2 (after vk_bn_bwd_coeffs): dz = a*g + b*z + c ; optional g_out (+)= g  (identity shortcut). */
 int vk_bn_bwd_reduce(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
                      const float* scale, const float* shift, const void* mask_src, double* sums, void* stream);
@@ -158,6 +173,9 @@ int vk_head_fwd(vk_dtype dtype, int N, int H, int W, const vk_src* src, const fl
                 float* logits, void* stream);
 int vk_head_bwd(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* dlogits,
                 void* dy, float* dw9x16, float* dbias, void* stream);
+/* same, with the BatchNorm+ReLU backward reduce of the head's input layer fused into the dy kernel (see vk_bnr) */
+int vk_head_bwd_fused(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* dlogits,
+                      void* dy, float* dw9x16, float* dbias, const vk_bnr* bnr, void* stream);
 
 /* loss = mean BCE-with-logits + binary Dice (smp defaults: batch-global, smooth 0, eps 1e-7).
  * sums: double[8] scratch (zeroed by the call).  loss_out[0] = w_bce*bce + w_dice*dice, [1] = bce, [2] = dice.

@@ -268,6 +268,45 @@ def test_conv_dgrad_pool2(shape, dtn):
         assert (from_nhwc(y1) - ref[:, Cup:]).abs().max().item() <= tol(dt, ref)
 
 
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("pool2", [0, 1])
+def test_conv_dgrad_fused_bn_relu_reduce(dtn, pool2):
+    """dgrad whose epilogue already applies the ReLU mask of the layer below and accumulates the BN-backward sums."""
+    dt = DT[dtn]
+    N, H, Cc, K = 2, 24, 64, 32
+    Hz = H // 2 if pool2 else H
+    w = gen(K, Cc, 3, 3, seed=241, scale=0.05)
+    dz = gen(N, K, H, H, seed=242)
+    zb = rnd(gen(N, Cc, Hz, Hz, seed=243), dt)                 # raw output of the layer below
+    g = torch.Generator().manual_seed(244)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    xin = torch.zeros(N, Cc, H, H, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, rnd(w, dt).double(), padding=1).backward(rnd(dz, dt).double())
+    dy = xin.grad.float()
+    if pool2:
+        dy = F.avg_pool2d(dy, 2) * 4.0
+    dy = rnd(dy, dt)
+    mask = (zb * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) > 0
+    gref = dy * mask
+    dzd, zbd = to_nhwc(dz, dt), to_nhwc(zb, dt)
+    wt = D(w.permute(1, 2, 3, 0).contiguous().to(dt))
+    y = torch.full((N, Hz, Hz, Cc), float("nan"), dtype=dt, device=dev())
+    sums = torch.zeros(REPL * 2 * Cc, dtype=torch.float64, device=dev())
+    scd, shd = D(sc), D(sh)
+    bnr = L_.vk_bnr(zbd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sums.data_ptr())
+    d = conv_desc(dt, N, H, H, H, H, Cc, 3, 1, 1, 1, mk_src(dzd, K))
+    vk._lib.check(vk.lib().vk_conv_dgrad_fused(C.byref(d), wt.data_ptr(), y.data_ptr(), None, 0, pool2, C.byref(bnr), st()))
+    torch.cuda.synchronize()
+    got = from_nhwc(y)
+    # elements whose pre-activation is within rounding of 0 may flip; compare where the mask is decided robustly
+    pre = (zb * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).abs() > 1e-4
+    assert ((got - gref).abs() * pre).max().item() <= tol(dt, dy) * 1.5
+    ss = sums.cpu().view(REPL, 2 * Cc).sum(0)
+    gg = got.double()
+    assert torch.allclose(ss[:Cc], gg.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3 * gg.abs().max().item() * 30)
+    assert torch.allclose(ss[Cc:], (gg * zb.double()).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3 * gg.abs().max().item() * 30)
+
+
 # ------------------------------------------------------------------------------------------------ wgrad
 WGRAD_CASES = [
     ("l1", 2, 24, 64, 64, 3, 1, 1),
@@ -467,7 +506,7 @@ def test_bn_relu_backward(dtn, mask_mode):
     invstd = 1.0 / torch.sqrt(var + 1e-5)
     scale = D((gamma.double() * invstd).float())
     shift = D((beta.double() - mean * gamma.double() * invstd).float())
-    sums = torch.zeros(2 * Cc, dtype=torch.float64, device=dev())
+    sums = torch.zeros(REPL * 2 * Cc, dtype=torch.float64, device=dev())
     zd, dyd = to_nhwc(z, dt), to_nhwc(dy, dt)
     outd = to_nhwc(out.detach().float(), dt)
     code = L_.dtype_code(dt)
@@ -483,7 +522,7 @@ def test_bn_relu_backward(dtn, mask_mode):
                                            shift.data_ptr(), outd.data_ptr(), coef.data_ptr(), dz.data_ptr(), gout.data_ptr(), 0, st()))
     torch.cuda.synchronize()
     rt = 1e-4 if dt == torch.float32 else 2e-2
-    assert (dgam.cpu() - gam.grad.float()).abs().max().item() <= rt * gam.grad.abs().max().item() + 1e-4
+    assert (dgam.cpu() - gam.grad.float()).abs().max().item() <= rt * gam.grad.abs().max().item() + 1e-4   # (coeffs kernel sums the replicas)
     assert (dbet.cpu() - bet.grad.float()).abs().max().item() <= rt * bet.grad.abs().max().item() + 1e-4
     ref = zr.grad.float()
     assert (from_nhwc(dz) - ref).abs().max().item() <= (2e-4 if dt == torch.float32 else 2e-2) * ref.abs().max().item()

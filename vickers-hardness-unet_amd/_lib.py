@@ -31,6 +31,10 @@ class vk_conv_desc(C.Structure):
                 ("pad", C.c_int), ("transposed", C.c_int), ("src0", vk_src), ("src1", vk_src)]
 
 
+class vk_bnr(C.Structure):
+    _fields_ = [("z", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("sums", C.c_void_p)]
+
+
 class vk_unet_config(C.Structure):
     _fields_ = [("N", C.c_int), ("size", C.c_int), ("dtype", C.c_int), ("training", C.c_int)]
 
@@ -52,6 +56,8 @@ SIGNATURES = {
     "vk_prof_collect": (ci, [C.c_char_p, sz]),
     "vk_conv_fwd": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp, vp]),
     "vk_conv_dgrad_pool2": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp]),
+    "vk_conv_dgrad_fused": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, P(vk_bnr), vp]),
+    "vk_head_bwd_fused": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp, vp, P(vk_bnr), vp]),
     "vk_stem_fwd": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     "vk_conv_wgrad": (ci, [P(vk_conv_desc), vp, vp, vp, sz, vp]),
     "vk_stem_wgrad": (ci, [ci, ci, ci, ci, vp, vp, vp, vp]),

@@ -39,6 +39,12 @@ struct HaloParams {
   double* stats;
   int N, H, W, K, C, flip, accumulate, pool2;
   int tiles_x, tiles_y, nchunks;
+  // fused BatchNorm+ReLU backward reduce on the first output part: g = y * [z*scale+shift > 0] is stored instead of y and
+  // sum(g), sum(g*z) go to bnr_sums [VK_STATS_REPLICAS][2][ld0]
+  const void* bnr_z;
+  const float* bnr_scale;
+  const float* bnr_shift;
+  double* bnr_sums;
 };
 
 template <typename T, int TH, int BN, int WGM, int WGN>
@@ -114,6 +120,39 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
   float s1[VE], s2[VE];
 #pragma unroll
   for (int j = 0; j < VE; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  const bool bnr = p.bnr_z != nullptr && first_part && col_ok;
+  float bsc[VE], bsh[VE];
+  if (bnr) {
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { bsc[j] = p.bnr_scale[colx + j]; bsh[j] = p.bnr_shift[colx + j]; }
+  }
+  // final value of one output vector: optional accumulate, optional BN+ReLU-backward masking + sums, store
+  auto finish = [&](float (&f)[VE], size_t elem_off) {
+    u32x4_t* gp = reinterpret_cast<u32x4_t*>(yb + elem_off * EB);
+    if (p.accumulate) {
+      float o[VE];
+      Vec16<T>::unpack(*gp, o);
+#pragma unroll
+      for (int j = 0; j < VE; ++j) f[j] += o[j];
+    }
+    u32x4_t v = Vec16<T>::pack(f);
+    Vec16<T>::unpack(v, f);                      // statistics are over the STORED (rounded) values
+    if (bnr) {
+      float zf[VE];
+      Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>((const char*)p.bnr_z + elem_off * EB), zf);
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        if (!(fmaf(zf[j], bsc[j], bsh[j]) > 0.f)) f[j] = 0.f;
+        s1[j] += f[j];
+        s2[j] += f[j] * zf[j];
+      }
+      v = Vec16<T>::pack(f);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VE; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
+    }
+    *gp = v;
+  };
   if (p.pool2 && first_part) {
     // (TH/2) x 8 pooled pixels; tile origins are even, H and W are even
     const int Hh = p.H >> 1, Wh = p.W >> 1;
@@ -132,14 +171,7 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
 #pragma unroll
           for (int j = 0; j < VE; ++j) f[j] += t[j];
         }
-        u32x4_t* gp = reinterpret_cast<u32x4_t*>(yb + ((((size_t)n * Hh + y) * Wh + x) * ld + colx) * EB);
-        if (p.accumulate) {
-          float o[VE];
-          Vec16<T>::unpack(*gp, o);
-#pragma unroll
-          for (int j = 0; j < VE; ++j) f[j] += o[j];
-        }
-        *gp = Vec16<T>::pack(f);
+        finish(f, (((size_t)n * Hh + y) * Wh + x) * ld + colx);
       }
     }
   } else {
@@ -148,26 +180,17 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
       const int row = e_row + ps * ERPP;          // tile pixel index
       const int y = y0 + (row >> 4), x = x0 + (row & 15);
       if (y < p.H && x < p.W && col_ok) {
-        const size_t m = ((size_t)n * p.H + y) * p.W + x;
-        u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + row * ESB + e_vec * 16);
-        u32x4_t* gp = reinterpret_cast<u32x4_t*>(yb + (m * ld + colx) * EB);
         float f[VE];
-        Vec16<T>::unpack(v, f);
-        if (p.accumulate) {
-          float o[VE];
-          Vec16<T>::unpack(*gp, o);
-#pragma unroll
-          for (int j = 0; j < VE; ++j) f[j] += o[j];
-          v = Vec16<T>::pack(f);
-          Vec16<T>::unpack(v, f);
-        }
-#pragma unroll
-        for (int j = 0; j < VE; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
-        *gp = v;
+        Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(smem + row * ESB + e_vec * 16), f);
+        finish(f, (((size_t)n * p.H + y) * p.W + x) * ld + colx);
       }
     }
   }
-  if (p.stats) {
+  if (p.stats || p.bnr_sums) {
+    if (p.bnr_sums && !bnr) {       // threads outside the first output part contribute nothing to the BN sums
+#pragma unroll
+      for (int j = 0; j < VE; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    }
 #pragma unroll
     for (int j = 0; j < VE; ++j) {
 #pragma unroll
@@ -189,9 +212,18 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
       float a = 0.f, b = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
-      double* sp = p.stats + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * p.K;
-      atomicAdd(sp + n0 + tid, (double)a);
-      atomicAdd(sp + p.K + n0 + tid, (double)b);
+      if (p.bnr_sums) {
+        const int kc = p.ld0;          // channel count of the first output part
+        if (n0 + tid < kc) {
+          double* sp = p.bnr_sums + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * kc;
+          atomicAdd(sp + n0 + tid, (double)a);
+          atomicAdd(sp + kc + n0 + tid, (double)b);
+        }
+      } else {
+        double* sp = p.stats + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * p.K;
+        atomicAdd(sp + n0 + tid, (double)a);
+        atomicAdd(sp + p.K + n0 + tid, (double)b);
+      }
     }
   }
 }
@@ -583,7 +615,7 @@ static int launch_c16(HaloParams p, hipStream_t st) {
 
 // returns VK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the tap-by-tap kernel)
 int conv3x3_halo_try(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate, double* stats,
-                     int pool2, hipStream_t st) {
+                     int pool2, const vk_bnr* bnr, hipStream_t st) {
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->H != d->Ho || d->W != d->Wo) return VK_ERR_UNSUPPORTED;
   const int eb = d->dtype == VK_F32 ? 4 : 2;
   const int ck = 64 / eb;
@@ -614,6 +646,10 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, void* y, void* y1, in
   p.flip = d->transposed;
   p.accumulate = accumulate;
   p.pool2 = pool2;
+  p.bnr_z = bnr ? bnr->z : nullptr;
+  p.bnr_scale = bnr ? bnr->scale : nullptr;
+  p.bnr_shift = bnr ? bnr->shift : nullptr;
+  p.bnr_sums = bnr ? bnr->sums : nullptr;
   p.nchunks = c16 ? 1 : C / ck;
   if (c16) {
     if (d->dtype == VK_BF16) return d->K >= 32 ? launch_c16<bf16_t, 32>(p, st) : launch_c16<bf16_t, 16>(p, st);

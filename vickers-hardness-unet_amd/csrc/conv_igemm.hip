@@ -470,7 +470,7 @@ static int dispatch(vk_dtype dt, const ConvParams& p, int mode, hipStream_t st) 
 }
 
 int conv3x3_halo_try(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate, double* stats,
-                     int pool2, hipStream_t st);
+                     int pool2, const vk_bnr* bnr, hipStream_t st);
 
 static bool halo_enabled() {
   static const bool on = getenv("VK_NO_HALO") == nullptr;
@@ -478,7 +478,7 @@ static bool halo_enabled() {
 }
 
 int conv_fwd_impl(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate,
-                  double* stats, int pool2, hipStream_t st) {
+                  double* stats, int pool2, const vk_bnr* bnr, hipStream_t st) {
   VK_CHECK_ARG(d && w && y, "vk_conv_fwd: null argument");
   const int eb = d->dtype == VK_F32 ? 4 : 2;
   const int ve = 16 / eb;
@@ -498,11 +498,11 @@ int conv_fwd_impl(const vk_conv_desc* d, const void* w, void* y, void* y1, int s
   VK_CHECK_ARG(!(d->src1.ptr && d->src1.up), "vk_conv_fwd: only src0 may be upsampled");
   if (halo_enabled() && (!d->transposed || d->stride == 1)) {
     // 3x3 stride-1 convolutions (and their data gradients) go to the LDS-staged halo kernel
-    const int rc = conv3x3_halo_try(d, w, y, y1, split_k1, accumulate, stats, pool2, st);
+    const int rc = conv3x3_halo_try(d, w, y, y1, split_k1, accumulate, stats, pool2, bnr, st);
     if (rc != VK_ERR_UNSUPPORTED) return rc;
   }
-  if (pool2) {
-    vkh::set_error("vk_conv_fwd: pooled (upsample-backward) output is only available on the 3x3 stride-1 tile kernels");
+  if (pool2 || bnr) {
+    vkh::set_error("vk_conv_dgrad_fused: pooled / BN-fused outputs are only available on the 3x3 stride-1 tile kernels");
     return VK_ERR_UNSUPPORTED;
   }
   ConvParams p;
@@ -570,12 +570,18 @@ int stem_fwd_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void* 
 
 extern "C" int vk_conv_fwd(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate,
                            double* stats, void* stream) {
-  return vk::conv_fwd_impl(d, w, y, y1, split_k1, accumulate, stats, 0, (hipStream_t)stream);
+  return vk::conv_fwd_impl(d, w, y, y1, split_k1, accumulate, stats, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int vk_conv_dgrad_pool2(const vk_conv_desc* d, const void* w, void* y_half, void* y1, int split_k1, int accumulate,
                                    void* stream) {
-  return vk::conv_fwd_impl(d, w, y_half, y1, split_k1, accumulate, nullptr, 1, (hipStream_t)stream);
+  return vk::conv_fwd_impl(d, w, y_half, y1, split_k1, accumulate, nullptr, 1, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int vk_conv_dgrad_fused(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int pool2, const vk_bnr* bnr,
+                                   void* stream) {
+  VK_CHECK_ARG(!bnr || (bnr->z && bnr->scale && bnr->shift && bnr->sums), "vk_conv_dgrad_fused: incomplete vk_bnr");
+  return vk::conv_fwd_impl(d, w, y, y1, split_k1, 0, nullptr, pool2, bnr, (hipStream_t)stream);
 }
 
 extern "C" int vk_stem_fwd(vk_dtype dtype, int N, int H, int W, const void* x4, const void* wp, void* y,

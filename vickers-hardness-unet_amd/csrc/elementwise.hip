@@ -309,18 +309,30 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(size_t pixels, int C, con
       a += red[(t * VE + cj) * 2];
       b += red[(t * VE + cj) * 2 + 1];
     }
-    atomicAdd(sums + c, a);
-    atomicAdd(sums + C + c, b);
+    double* sp = sums + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * C;
+    atomicAdd(sp + c, a);
+    atomicAdd(sp + C + c, b);
   }
 }
 
-__global__ void k_bn_bwd_coeffs(int C, const double* __restrict__ sums, double count, const float* __restrict__ gamma,
-                                const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* dgamma,
-                                float* dbeta, float* coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void k_bn_bwd_coeffs(int C, const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                                       const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* dgamma,
+                                                       float* dbeta, float* coef) {
+  // 8 channels per workgroup; the 32 lanes of a half-wave each fetch one replica of the partial sums
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int q = threadIdx.x & 31;
+  double sg = 0.0, sgz = 0.0;
+  if (c < C) {
+    sg = sums[(size_t)q * 2 * C + c];
+    sgz = sums[(size_t)q * 2 * C + C + c];
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    sg += __shfl_xor(sg, o, 64);
+    sgz += __shfl_xor(sgz, o, 64);
+  }
+  if (q != 0 || c >= C) return;
   const double mu = save_mean[c], r = save_invstd[c], ga = gamma[c];
-  const double sg = sums[c], sgz = sums[C + c];
   const double dg = r * (sgz - mu * sg);     // sum g * xhat
   const double db = sg;
   dgamma[c] += (float)dg;
@@ -352,25 +364,42 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(size_t pixels, int C, cons
   const int c0 = (int)(t0 % CV) * VE;
   // per-workgroup coefficient table in LDS (one thread per channel), so the per-thread prologue is 3 LDS reads / channel
   __shared__ float cf[3][512];
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    if (coef) {
+  if (coef) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
       cf[0][c] = coef[c];
       cf[1][c] = coef[C + c];
       cf[2][c] = coef[2 * C + c];
-    } else {
-      // only the cancelling difference needs fp64 (one DFMA per channel); the rest is fp32
-      const float mu = save_mean[c], r = save_invstd[c], ga = gamma[c];
-      const double sg = sums[c];
-      const float d = (float)(sums[C + c] - (double)mu * sg);
-      const float sgf = (float)sg, inv = (float)(1.0 / count);
-      const float dg = r * d;
-      const float a = ga * r, b = -a * r * dg * inv;
-      cf[0][c] = a;
-      cf[1][c] = b;
-      cf[2][c] = -a * sgf * inv - b * mu;
-      if (blockIdx.x == 0) {
-        dgamma[c] += dg;
-        dbeta[c] += sgf;
+    }
+  } else {
+    // 8 threads per channel add 4 of the 32 replicas each, then an 8-lane butterfly
+    static_assert(VK_STATS_REPLICAS == 32, "replica mapping");
+    for (int c8 = threadIdx.x; c8 < C * 8; c8 += blockDim.x) {
+      const int c = c8 >> 3, q0 = (c8 & 7) * 4;
+      double sg = 0.0, sgz = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        sg += sums[(size_t)(q0 + q) * 2 * C + c];
+        sgz += sums[(size_t)(q0 + q) * 2 * C + C + c];
+      }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) {
+        sg += __shfl_xor(sg, o, 64);
+        sgz += __shfl_xor(sgz, o, 64);
+      }
+      if ((c8 & 7) == 0) {
+        // only the cancelling difference needs fp64 (one DFMA per channel); the rest is fp32
+        const float mu = save_mean[c], r = save_invstd[c], ga = gamma[c];
+        const float d = (float)(sgz - (double)mu * sg);
+        const float sgf = (float)sg, inv = (float)(1.0 / count);
+        const float dg = r * d;
+        const float a = ga * r, b = -a * r * dg * inv;
+        cf[0][c] = a;
+        cf[1][c] = b;
+        cf[2][c] = -a * sgf * inv - b * mu;
+        if (blockIdx.x == 0) {
+          dgamma[c] += dg;
+          dbeta[c] += sgf;
+        }
       }
     }
   }
@@ -525,40 +554,80 @@ __global__ __launch_bounds__(256) void k_head_fwd(int N, int H, int W, int tiles
 
 // ---- backward, data: dy[m][c] = sum_tap dl[m + (1-r, 1-s)] * w[tap][c]
 template <typename T>
-__global__ __launch_bounds__(256) void k_head_dgrad(int N, int H, int W, int tiles_x, int tiles_y, const float* __restrict__ w,
-                                                    const float* __restrict__ dl, T* __restrict__ dy) {
+__global__ __launch_bounds__(256) void k_head_dgrad(int N, int H, int W, int tiles_x, int tiles_y, int ntiles, const float* __restrict__ w,
+                                                    const float* __restrict__ dl, T* __restrict__ dy, const T* __restrict__ bnr_z,
+                                                    const float* __restrict__ bnr_scale, const float* __restrict__ bnr_shift, double* bnr_sums) {
   constexpr int VE = ElemTraits<T>::kVec;
-  __shared__ float dt[18 * 18];
-  const int tid = threadIdx.x;
-  int bt = blockIdx.x;
-  const int tx0 = bt % tiles_x;
-  bt /= tiles_x;
-  const int ty0 = bt % tiles_y;
-  const int n = bt / tiles_y;
-  const int y0 = ty0 * 16, x0 = tx0 * 16;
-  for (int hp = tid; hp < 324; hp += 256) {
-    const int hy = hp / 18, hx = hp - hy * 18;
-    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-    dt[hp] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? dl[((size_t)n * H + y) * W + x] : 0.f;
+  __shared__ float dt[2][18 * 18];
+  __shared__ float bred[4][32];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  float s1[16], s2[16], bsc[16], bsh[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    s1[j] = 0.f; s2[j] = 0.f;
+    bsc[j] = bnr_z ? bnr_scale[j] : 1.f;
+    bsh[j] = bnr_z ? bnr_shift[j] : 0.f;
   }
-  __syncthreads();
-  const int ty = tid >> 4, tx = tid & 15;
-  float o[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) o[j] = 0.f;
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const float d = dt[(ty + 2 - r) * 18 + tx + 2 - s];      // halo origin is (y0-1, x0-1): pixel + (1 - r, 1 - s)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) o[j] = fmaf(d, w[(r * 3 + s) * 16 + j], o[j]);
+  int it = 0;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
+    int bt = t;
+    const int tx0 = bt % tiles_x;
+    bt /= tiles_x;
+    const int ty0 = bt % tiles_y;
+    const int n = bt / tiles_y;
+    const int y0 = ty0 * 16, x0 = tx0 * 16;
+    float* d = dt[it & 1];
+    for (int hp = tid; hp < 324; hp += 256) {
+      const int hy = hp / 18, hx = hp - hy * 18;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      d[hp] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? dl[((size_t)n * H + y) * W + x] : 0.f;
     }
-  const int y = y0 + ty, x = x0 + tx;
-  if (y < H && x < W) {
-    T* dst = dy + (((size_t)n * H + y) * W + x) * 16;
+    __syncthreads();                 // (double-buffered tile: the other buffer was last read two iterations ago)
+    float o[16];
 #pragma unroll
-    for (int v = 0; v < 16 / VE; ++v) *reinterpret_cast<u32x4_t*>(dst + v * VE) = Vec16<T>::pack(o + v * VE);
+    for (int j = 0; j < 16; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const float dv = d[(ty + 2 - r) * 18 + tx + 2 - s];      // halo origin is (y0-1, x0-1): pixel + (1 - r, 1 - s)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] = fmaf(dv, w[(r * 3 + s) * 16 + j], o[j]);
+      }
+    const int y = y0 + ty, x = x0 + tx;
+    if (y < H && x < W) {
+      const size_t off = (((size_t)n * H + y) * W + x) * 16;
+#pragma unroll
+      for (int v = 0; v < 16 / VE; ++v) {
+        u32x4_t pk = Vec16<T>::pack(o + v * VE);
+        if (bnr_z) {       // g = dy * [relu(bn(z)) > 0]; sums over the stored values
+          float g[VE], zf[VE];
+          Vec16<T>::unpack(pk, g);
+          Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(bnr_z + off + v * VE), zf);
+#pragma unroll
+          for (int j = 0; j < VE; ++j) {
+            if (!(fmaf(zf[j], bsc[v * VE + j], bsh[v * VE + j]) > 0.f)) g[j] = 0.f;
+            s1[v * VE + j] += g[j];
+            s2[v * VE + j] += g[j] * zf[j];
+          }
+          pk = Vec16<T>::pack(g);
+        }
+        *reinterpret_cast<u32x4_t*>(dy + off + v * VE) = pk;
+      }
+    }
+  }
+  if (bnr_z) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float a = wave_sum(s1[j]), b = wave_sum(s2[j]);
+      if (lane == 0) { bred[wave][j] = a; bred[wave][16 + j] = b; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const float v = bred[0][tid] + bred[1][tid] + bred[2][tid] + bred[3][tid];
+      atomicAdd(bnr_sums + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 32 + tid, (double)v);   // [replica][2][16]
+    }
   }
 }
 
@@ -811,7 +880,7 @@ extern "C" int vk_bn_bwd_coeffs(int C, const double* sums, double count, const f
                                 const float* save_invstd, float* dgamma, float* dbeta, float* coef_abc, void* stream) {
   VK_CHECK_ARG(sums && gamma && save_mean && save_invstd && dgamma && dbeta && coef_abc, "vk_bn_bwd_coeffs: null argument");
   vkh::ProfScope ps_("bn_bwd_coeffs", (hipStream_t)stream, 0.0, (double)C * 48.0);
-  hipLaunchKernelGGL(k_bn_bwd_coeffs, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, sums, count, gamma, save_mean,
+  hipLaunchKernelGGL(k_bn_bwd_coeffs, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, C, sums, count, gamma, save_mean,
                      save_invstd, dgamma, dbeta, coef_abc);
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
@@ -890,8 +959,22 @@ extern "C" int vk_head_fwd(vk_dtype dtype, int N, int H, int W, const vk_src* sr
   return VK_OK;
 }
 
+static int head_bwd_impl(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* dlogits,
+                         void* dy, float* dw9x16, float* dbias, const vk_bnr* bnr, void* stream);
+
 extern "C" int vk_head_bwd(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* dlogits,
                            void* dy, float* dw9x16, float* dbias, void* stream) {
+  return head_bwd_impl(dtype, N, H, W, src, w9x16, dlogits, dy, dw9x16, dbias, nullptr, stream);
+}
+
+extern "C" int vk_head_bwd_fused(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* dlogits,
+                                 void* dy, float* dw9x16, float* dbias, const vk_bnr* bnr, void* stream) {
+  VK_CHECK_ARG(bnr && bnr->z && bnr->scale && bnr->shift && bnr->sums, "vk_head_bwd_fused: incomplete vk_bnr");
+  return head_bwd_impl(dtype, N, H, W, src, w9x16, dlogits, dy, dw9x16, dbias, bnr, stream);
+}
+
+static int head_bwd_impl(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* dlogits,
+                         void* dy, float* dw9x16, float* dbias, const vk_bnr* bnr, void* stream) {
   VK_CHECK_ARG(src && src->ptr && w9x16 && dlogits && dy && dw9x16 && dbias, "vk_head_bwd: null argument");
   VK_CHECK_ARG(src->C == 16 && !src->up, "vk_head_bwd: head input must have 16 channels, no upsample");
   hipStream_t st = (hipStream_t)stream;
@@ -900,7 +983,10 @@ extern "C" int vk_head_bwd(vk_dtype dtype, int N, int H, int W, const vk_src* sr
   const double eb = dtype == VK_F32 ? 4.0 : 2.0;
   {
     vkh::ProfScope ps_("head_dgrad", st, 2.0 * 144.0 * N * H * W, (double)N * H * W * (16.0 * eb + 4.0));
-    DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_dgrad<T>, dim3((unsigned)ntiles), dim3(256), 0, st, N, H, W, tx, ty, w9x16, dlogits, (T*)dy));
+    const int nbd = ntiles < 2048 ? ntiles : 2048;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_dgrad<T>, dim3((unsigned)nbd), dim3(256), 0, st, N, H, W, tx, ty, ntiles, w9x16, dlogits, (T*)dy,
+                                         (const T*)(bnr ? bnr->z : nullptr), bnr ? bnr->scale : nullptr, bnr ? bnr->shift : nullptr,
+                                         bnr ? bnr->sums : nullptr));
   }
   {
     vkh::ProfScope ps_("head_wgrad", st, 2.0 * 144.0 * N * H * W, (double)N * H * W * (16.0 * eb + 4.0));

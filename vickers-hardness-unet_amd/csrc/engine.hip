@@ -7,6 +7,7 @@
 // int64 num_batches_tracked) plus one workspace; this file only computes offsets into them.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -238,6 +239,7 @@ struct vk_unet {
   size_t off_stats = 0, off_bsums = 0, stats_bytes = 0, off_farena = 0, farena_floats = 0, off_wf = 0, off_wd = 0, off_wstem = 0;
   size_t off_tab_pack = 0, off_tab_bn = 0, off_wslab = 0;
   std::vector<size_t> off_z, off_g, off_out, off_gout;
+  std::vector<char> g_prereduced;      // per conv: its gradient buffer already holds masked g + sums (vk_bnr fusion)
   // bound pointers
   float* params = nullptr;
   float* grads = nullptr;
@@ -405,6 +407,7 @@ void layout_workspace(vk_unet* h) {
     return o;
   };
   h->off_x4 = take((size_t)N * S * S * 4 * eb);
+  h->g_prereduced.assign(h->convs.size(), 0);
   h->off_z.resize(h->convs.size());
   h->off_g.assign(h->convs.size(), 0);
   for (size_t i = 0; i < h->convs.size(); ++i) {
@@ -441,7 +444,7 @@ void layout_workspace(vk_unet* h) {
   }
   h->stats_bytes = st;
   h->off_stats = take(st);
-  h->off_bsums = take(st / VK_STATS_REPLICAS);
+  h->off_bsums = take(st);
   h->farena_floats = fl;
   h->off_farena = take(fl * sizeof(float));
   h->off_wf = (eb == 4) ? 0 : take((size_t)h->n_params * eb);
@@ -487,7 +490,7 @@ void assign_pointers(vk_unet* h) {
     b.stats = sp;
     b.bsums = bp;
     sp += 2 * b.C * VK_STATS_REPLICAS;
-    bp += 2 * b.C;
+    bp += 2 * b.C * VK_STATS_REPLICAS;
     float* f = fa + b.arena_off;
     b.scale = f;
     b.shift = f + b.C;
@@ -737,17 +740,48 @@ extern "C" int vk_unet_loss(vk_unet* h, const float* logits, const float* target
 namespace {
 
 // gradient wrt activated output (in c.g) -> gradient wrt z (in place); dgamma/dbeta accumulated
-int bn_relu_bwd_inplace(vk_unet* h, ConvL& c, hipStream_t st) {
+// prereduced: the producer of c.g already stored g = dy * mask and accumulated the sums (vk_bnr fusion)
+int bn_relu_bwd_inplace(vk_unet* h, ConvL& c, bool prereduced, hipStream_t st) {
   BnL& b = h->bns[c.bn];
   const size_t pixels = (size_t)h->cfg.N * c.Hout * c.Hout;
-  RET_IF(vk_bn_bwd_reduce(h->cfg.dtype, pixels, c.K, c.g, c.z, 1, b.scale, b.shift, nullptr, b.bsums, st));
-  return vk_bn_bwd_apply_fused(h->cfg.dtype, pixels, c.K, c.g, c.z, 1, b.scale, b.shift, nullptr, b.bsums, b.count, h->params + b.g_off, b.mean,
-                               b.invstd, h->grads + b.g_off, h->grads + b.b_off, c.g, nullptr, 0, st);
+  if (!prereduced) RET_IF(vk_bn_bwd_reduce(h->cfg.dtype, pixels, c.K, c.g, c.z, 1, b.scale, b.shift, nullptr, b.bsums, st));
+  RET_IF(vk_bn_bwd_coeffs(c.K, b.bsums, b.count, h->params + b.g_off, b.mean, b.invstd, h->grads + b.g_off, h->grads + b.b_off, b.coef, st));
+  return vk_bn_bwd_apply(h->cfg.dtype, pixels, c.K, c.g, c.z, prereduced ? 0 : 1, b.scale, b.shift, nullptr, b.coef, c.g, nullptr, 0, st);
 }
 
 int conv_wgrad(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, hipStream_t st) {
   vk_conv_desc d = conv_desc(h, c, s0, s1);
   return vk_conv_wgrad(&d, c.g, h->grads + c.w_off, h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, st);
+}
+
+vk_bnr bnr_of(vk_unet* h, ConvL& target) {     // fused BN+ReLU backward reduce descriptor for the layer `target`
+  BnL& b = h->bns[target.bn];
+  vk_bnr r;
+  r.z = target.z; r.scale = b.scale; r.shift = b.shift; r.sums = b.bsums;
+  return r;
+}
+
+vk_conv_desc dgrad_desc(vk_unet* h, ConvL& c) {
+  vk_conv_desc d;
+  d.dtype = h->cfg.dtype;
+  d.N = h->cfg.N; d.H = c.Hout; d.W = c.Hout; d.Ho = c.Hin; d.Wo = c.Hin;
+  d.K = c.Cin; d.R = c.R; d.S = c.R; d.stride = c.stride; d.pad = c.pad; d.transposed = 1;
+  vk_src s;
+  s.ptr = c.g; s.C = c.K; s.up = 0; s.scale = nullptr; s.shift = nullptr; s.relu = 0;
+  d.src0 = s;
+  d.src1 = null_src();
+  return d;
+}
+
+// dgrad of conv c written to `into.g`, with the BN+ReLU backward reduce of layer `into` fused when the tile kernels
+// cover the shape; *fused tells the caller whether that happened
+int conv_dgrad_into(vk_unet* h, ConvL& c, ConvL& into, bool* fused, hipStream_t st) {
+  vk_conv_desc d = dgrad_desc(h, c);
+  vk_bnr r = bnr_of(h, into);
+  int rc = getenv("VK_NO_BNR_FUSION") ? VK_ERR_UNSUPPORTED : vk_conv_dgrad_fused(&d, dgrad_weights(h, c), into.g, nullptr, 0, 0, &r, st);
+  *fused = rc == VK_OK;
+  if (rc != VK_ERR_UNSUPPORTED) return rc;
+  return vk_conv_fwd(&d, dgrad_weights(h, c), into.g, nullptr, 0, 0, nullptr, st);
 }
 
 // dx = dgrad(dz of conv c) into y (and y1 for the channel split)
@@ -790,25 +824,26 @@ int backward_decoder(vk_unet* h, int i, hipStream_t st) {
     skip = bn_act(h, stem);
     g_skip = stem.g;
   }
-  // conv2 unit
-  RET_IF(bn_relu_bwd_inplace(h, c2, st));
+  // conv2 unit (its gradient was pre-masked/pre-reduced by the producer when that kernel supports the fusion)
+  RET_IF(bn_relu_bwd_inplace(h, c2, h->g_prereduced[d.conv2] != 0, st));
   RET_IF(conv_wgrad(h, c2, to_src(bn_act(h, c1)), null_src(), st));
-  RET_IF(conv_dgrad(h, c2, c1.g, nullptr, 0, 0, st));
+  bool fused1 = false;
+  RET_IF(conv_dgrad_into(h, c2, c1, &fused1, st));
   // conv1 unit
-  RET_IF(bn_relu_bwd_inplace(h, c1, st));
+  RET_IF(bn_relu_bwd_inplace(h, c1, fused1, st));
   RET_IF(conv_wgrad(h, c1, to_src(xprev, 1), d.Cskip ? to_src(skip) : null_src(), st));
-  // data gradient with the nearest-x2 upsample backward fused into its epilogue (the full-resolution d_up never exists);
+  // data gradient with the nearest-x2 upsample backward fused into its epilogue (the full-resolution d_up never exists)
+  // and, for i > 0, the BN+ReLU backward reduce of the previous decoder block's conv2;
   // shapes the tile kernels do not cover fall back to dgrad + a separate 2x2-sum pass
+  if (i > 0) h->g_prereduced[h->decs[i - 1].conv2] = 0;
   {
-    vk_conv_desc dd;
-    dd.dtype = h->cfg.dtype;
-    dd.N = N; dd.H = c1.Hout; dd.W = c1.Hout; dd.Ho = c1.Hin; dd.Wo = c1.Hin;
-    dd.K = c1.Cin; dd.R = c1.R; dd.S = c1.R; dd.stride = 1; dd.pad = c1.pad; dd.transposed = 1;
-    vk_src s;
-    s.ptr = c1.g; s.C = c1.K; s.up = 0; s.scale = nullptr; s.shift = nullptr; s.relu = 0;
-    dd.src0 = s;
-    dd.src1 = null_src();
-    const int rc = vk_conv_dgrad_pool2(&dd, dgrad_weights(h, c1), g_prev, d.Cskip ? g_skip : nullptr, d.Cskip ? d.Cup : 0, 0, st);
+    vk_conv_desc dd = dgrad_desc(h, c1);
+    vk_bnr r;
+    const bool want_bnr = i > 0 && !getenv("VK_NO_BNR_FUSION");
+    if (want_bnr) r = bnr_of(h, h->convs[h->decs[i - 1].conv2]);
+    const int rc = vk_conv_dgrad_fused(&dd, dgrad_weights(h, c1), g_prev, d.Cskip ? g_skip : nullptr, d.Cskip ? d.Cup : 0, 1,
+                                       want_bnr ? &r : nullptr, st);
+    if (rc == VK_OK && want_bnr) h->g_prereduced[h->decs[i - 1].conv2] = 1;
     if (rc != VK_ERR_UNSUPPORTED) return rc;
   }
   void* dup = h->ws + h->off_dup;
@@ -839,22 +874,23 @@ int backward_block(vk_unet* h, int bi, hipStream_t st) {
   RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.bsums, st));
   if (k.convd < 0) {
     // identity shortcut: gin (+)= g
-    RET_IF(vk_bn_bwd_apply_fused(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd,
-                                 h->grads + b2.g_off, h->grads + b2.b_off, c2.g, gin, k.in_has_grad_first ? 1 : 0, st));
+    RET_IF(vk_bn_bwd_coeffs(k.C, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd, h->grads + b2.g_off, h->grads + b2.b_off, b2.coef, st));
+    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.coef, c2.g, gin, k.in_has_grad_first ? 1 : 0, st));
   } else {
     ConvL& cd = h->convs[k.convd];
     BnL& bd = h->bns[cd.bn];
-    RET_IF(vk_bn_bwd_apply_fused(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd,
-                                 h->grads + b2.g_off, h->grads + b2.b_off, c2.g, nullptr, 0, st));
+    RET_IF(vk_bn_bwd_coeffs(k.C, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd, h->grads + b2.g_off, h->grads + b2.b_off, b2.coef, st));
+    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.coef, c2.g, nullptr, 0, st));
     RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, cd.z, 2, nullptr, nullptr, k.out, bd.bsums, st));
-    RET_IF(vk_bn_bwd_apply_fused(dt, pixels, k.C, k.gout, cd.z, 2, nullptr, nullptr, k.out, bd.bsums, bd.count, h->params + bd.g_off, bd.mean, bd.invstd,
-                                 h->grads + bd.g_off, h->grads + bd.b_off, cd.g, nullptr, 0, st));
+    RET_IF(vk_bn_bwd_coeffs(k.C, bd.bsums, bd.count, h->params + bd.g_off, bd.mean, bd.invstd, h->grads + bd.g_off, h->grads + bd.b_off, bd.coef, st));
+    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, cd.z, 2, nullptr, nullptr, k.out, bd.coef, cd.g, nullptr, 0, st));
   }
   // conv2
   RET_IF(conv_wgrad(h, c2, to_src(bn_act(h, c1)), null_src(), st));
-  RET_IF(conv_dgrad(h, c2, c1.g, nullptr, 0, 0, st));
+  bool fused1 = false;
+  RET_IF(conv_dgrad_into(h, c2, c1, &fused1, st));
   // conv1
-  RET_IF(bn_relu_bwd_inplace(h, c1, st));
+  RET_IF(bn_relu_bwd_inplace(h, c1, fused1, st));
   RET_IF(conv_wgrad(h, c1, to_src(xin), null_src(), st));
   // gin was written by the identity shortcut above or (downsample blocks) by the decoder skip gradient
   RET_IF(conv_dgrad(h, c1, gin, nullptr, 0, 1, st));
@@ -871,7 +907,7 @@ int backward_stem(vk_unet* h, hipStream_t st) {
   ConvL& stem = h->convs[h->stem_conv];
   // stem.g holds the skip gradient of f1 (from decoder block 3); add the maxpool path
   RET_IF(vk_maxpool_bwd(h->cfg.dtype, N, S / 2, S / 2, 64, h->ws + h->off_gpool, (const uint8_t*)(h->ws + h->off_argmax), stem.g, st));
-  RET_IF(bn_relu_bwd_inplace(h, stem, st));
+  RET_IF(bn_relu_bwd_inplace(h, stem, false, st));
   return vk_stem_wgrad(h->cfg.dtype, N, S, S, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, st);
 }
 
@@ -879,11 +915,19 @@ int backward_stage(vk_unet* h, const float* dlogits, int stage, hipStream_t st) 
   const int N = h->cfg.N, S = h->cfg.size;
   switch (stage) {
     case 0: {
-      VK_CHECK_HIP(hipMemsetAsync(h->ws + h->off_bsums, 0, h->stats_bytes / VK_STATS_REPLICAS, st));
+      VK_CHECK_HIP(hipMemsetAsync(h->ws + h->off_bsums, 0, h->stats_bytes, st));
       ConvL& last = h->convs[h->decs[4].conv2];
       vk_src hs = to_src(bn_act(h, last));
-      RET_IF(vk_head_bwd(h->cfg.dtype, N, S, S, &hs, h->params + h->head_w_off, dlogits ? dlogits : (const float*)(h->ws + h->off_dlogits), last.g,
-                         h->grads + h->head_w_off, h->grads + h->head_b_off, st));
+      {
+        vk_bnr r = bnr_of(h, last);
+        const bool fuse = !getenv("VK_NO_BNR_FUSION");
+        const float* dl = dlogits ? dlogits : (const float*)(h->ws + h->off_dlogits);
+        if (fuse) RET_IF(vk_head_bwd_fused(h->cfg.dtype, N, S, S, &hs, h->params + h->head_w_off, dl, last.g, h->grads + h->head_w_off,
+                                           h->grads + h->head_b_off, &r, st));
+        else RET_IF(vk_head_bwd(h->cfg.dtype, N, S, S, &hs, h->params + h->head_w_off, dl, last.g, h->grads + h->head_w_off,
+                                h->grads + h->head_b_off, st));
+        h->g_prereduced[h->decs[4].conv2] = fuse ? 1 : 0;
+      }
       RET_IF(backward_decoder(h, 4, st));
       RET_IF(backward_decoder(h, 3, st));
       return backward_decoder(h, 2, st);
