@@ -52,6 +52,8 @@ int vk_has_gfx950_code(void);
  * by two hipEvents on its own stream.  vk_prof_collect synchronises those events and writes one line per
  * kernel family into buf: "tag count total_ms total_algorithmic_flops total_algorithmic_bytes\n";
  * returns the number of bytes written (or <0).  Used by bench.py for the live roofline figure. */
+/* diagnostic builds only (make stamp): buffer receiving per-wave s_memtime segment totals of the tile kernels */
+int vk_debug_set_stamp_buffer(void* device_buffer);
 int vk_prof_enable(int on);
 int vk_prof_collect(char* buf, size_t buflen);
 
@@ -98,6 +100,17 @@ int vk_conv_fwd(const vk_conv_desc* d, const void* w, void* y, void* y1, int spl
  * vk_conv_fwd + vk_upsample2x_bwd). */
 int vk_conv_dgrad_pool2(const vk_conv_desc* d, const void* w, void* y_half, void* y1, int split_k1, int accumulate,
                         void* stream);
+
+/* The 3x3 stride-1 tile kernels read their weights in the "halo pack": [red/CK][9 taps][rows][CK] (CK = 64 bytes of
+ * channels), 16-byte pieces pre-swizzled for the LDS image, so that a pipeline stage is three linear 1-KiB-per-wave copies.
+ * vk_halo_pack builds it from plain [rows][3][3][red] weights of `dtype` (forward: rows = K, red = C; data gradient: the
+ * transposed weights, rows = C, red = K).  vk_conv_uses_halo_pack tells whether a descriptor runs on those kernels
+ * (then vk_conv_fwd_packed / vk_conv_dgrad_fused / vk_conv_dgrad_pool2 expect the pack; layers with C == 16 in a 16-bit
+ * type keep plain weights).  vk_conv_fwd with plain weights always works (tap-by-tap kernel) but is slower. */
+int vk_halo_pack(vk_dtype dtype, int rows, int red, const void* src, void* dst, void* stream);
+int vk_conv_uses_halo_pack(const vk_conv_desc* d);
+int vk_conv_fwd_packed(const vk_conv_desc* d, const void* w_halo, void* y, void* y1, int split_k1, int accumulate, double* stats,
+                       void* stream);
 
 /* BatchNorm+ReLU backward reduce fused into the kernel that produces the gradient: with y the gradient w.r.t. the
  * activated tensor relu(z*scale+shift), the kernel stores g = y * [z*scale+shift > 0] instead of y and adds sum(g),

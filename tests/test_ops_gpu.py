@@ -75,6 +75,40 @@ def conv_desc(dt, N, H, W, Ho, Wo, K, R, stride, pad, transposed, s0, s1=None):
     return L_.vk_conv_desc(L_.dtype_code(dt), N, H, W, Ho, Wo, K, R, R, stride, pad, transposed, s0, s1 or null_src())
 
 
+def conv_w(d, w):
+    """Weights as the conv entry points want them: the halo pack (vk_halo_pack) when the descriptor runs on the 3x3
+    tile kernels, the plain [rows][3][3][red] tensor otherwise.  Returns (tensor, packed)."""
+    lib = vk.lib()
+    if not lib.vk_conv_uses_halo_pack(C.byref(d)):
+        return w, False
+    red = d.src0.C + (d.src1.C if d.src1.ptr else 0)
+    pk = torch.empty_like(w)
+    KEEP.append(pk)
+    L_.check(lib.vk_halo_pack(d.dtype, d.K, red, w.data_ptr(), pk.data_ptr(), st()))
+    return pk, True
+
+
+def conv_run(d, w, y, y1=None, split=0, acc=0, stats=None, plain=False):
+    """vk_conv_fwd_packed on the tile kernels (plain=False and the shape is covered), vk_conv_fwd (tap-by-tap) otherwise."""
+    lib = vk.lib()
+    wp, packed = (w, False) if plain else conv_w(d, w)
+    fn = lib.vk_conv_fwd_packed if packed else lib.vk_conv_fwd
+    L_.check(fn(C.byref(d), wp.data_ptr(), y.data_ptr(), y1.data_ptr() if y1 is not None else None, split, acc,
+                stats.data_ptr() if stats is not None else None, st()))
+    return packed
+
+
+@pytest.fixture(params=["tile", "tile_alt1", "tile_alt2", "tile_alt3", "tap"])
+def conv_path(request, monkeypatch):
+    """tile: 3x3 stride-1 tile kernels with halo-pack weights (alt1..3: the other tile shapes of the K >= 128 class forced);
+    tap: the tap-by-tap implicit-GEMM kernel with plain weights."""
+    if request.param.startswith("tile_alt"):
+        monkeypatch.setenv("VK_COL_ALT", request.param[-1])
+    else:
+        monkeypatch.delenv("VK_COL_ALT", raising=False)
+    return request.param
+
+
 def gen(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
@@ -90,14 +124,19 @@ CONV_CASES = [
     ("dec3_c2", 1, 40, 32, 32, 3, 1, 1, True),
     ("dec4_c2_smallC", 1, 40, 16, 16, 3, 1, 1, True),
     ("odd_edges", 3, 13, 32, 48, 3, 1, 1, True),
+    ("l2_body", 2, 40, 128, 128, 3, 1, 1, True),
+    ("l3_ragged", 1, 27, 256, 256, 3, 1, 1, True),
+    ("k192", 1, 20, 64, 192, 3, 1, 1, False),
 ]
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_fwd(case, dtn):
+def test_conv_fwd(case, dtn, conv_path):
     dt = DT[dtn]
     _, N, H, Cc, K, R, stride, pad, affine = case
+    if conv_path.startswith("tile_alt") and K < 128:
+        pytest.skip("alternative tile shapes exist for K >= 128 only")
     Ho = (H + 2 * pad - R) // stride + 1
     x = gen(N, Cc, H, H, seed=1)
     w = gen(K, Cc, R, R, seed=2, scale=(2.0 / (Cc * R * R)) ** 0.5)
@@ -114,7 +153,7 @@ def test_conv_fwd(case, dtn):
     y = torch.full((N, Ho, Ho, K), float("nan"), dtype=dt, device=dev())
     stats = torch.zeros(REPL * 2 * K, dtype=torch.float64, device=dev())
     d = conv_desc(dt, N, H, H, Ho, Ho, K, R, stride, pad, 0, mk_src(xd, Cc, 0, sc, sh, 1 if affine else 0))
-    vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wd.data_ptr(), y.data_ptr(), None, 0, 0, stats.data_ptr(), st()))
+    conv_run(d, wd, y, stats=stats, plain=conv_path == "tap")
     torch.cuda.synchronize()
     got = from_nhwc(y)
     assert torch.isfinite(got).all()
@@ -130,10 +169,12 @@ def test_conv_fwd(case, dtn):
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 16, 64, 32, 32), (1, 8, 512, 256, 256), (1, 32, 32, 0, 16)],
                          ids=["d3", "d0", "d4_noskip"])
-def test_conv_fwd_upsample_concat(shape, dtn):
+def test_conv_fwd_upsample_concat(shape, dtn, conv_path):
     """decoder conv1: nearest x2 upsample of src0 (with BN+ReLU prologue) concatenated with a skip."""
     dt = DT[dtn]
     N, H, Cup, Cskip, K = shape
+    if conv_path.startswith("tile_alt") and K < 128:
+        pytest.skip("alternative tile shapes exist for K >= 128 only")
     lo = gen(N, Cup, H // 2, H // 2, seed=5)
     sc_c = 0.5 + torch.rand(Cup, generator=torch.Generator().manual_seed(6))
     sh_c = gen(Cup, seed=7, scale=0.3)
@@ -153,7 +194,7 @@ def test_conv_fwd_upsample_concat(shape, dtn):
     scd, shd = D(sc_c), D(sh_c)
     y = torch.empty((N, H, H, K), dtype=dt, device=dev())
     d = conv_desc(dt, N, H, H, H, H, K, 3, 1, 1, 0, mk_src(lod, Cup, 1, scd, shd, 1), s1)
-    vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wd.data_ptr(), y.data_ptr(), None, 0, 0, None, st()))
+    conv_run(d, wd, y, plain=conv_path == "tap")
     torch.cuda.synchronize()
     err = (from_nhwc(y) - ref).abs().max().item()
     assert err <= tol(dt, ref), err
@@ -189,14 +230,18 @@ DGRAD_CASES = [
     ("s2_1x1", 2, 24, 64, 128, 1, 2, 0),
     ("k16", 1, 40, 32, 16, 3, 1, 1),      # reduction over 16 output channels (small-C mode)
     ("k32", 1, 40, 128, 32, 3, 1, 1),
+    ("c128", 2, 24, 128, 128, 3, 1, 1),
+    ("c384_k128", 1, 36, 384, 128, 3, 1, 1),
 ]
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
 @pytest.mark.parametrize("case", DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
-def test_conv_dgrad(case, dtn):
+def test_conv_dgrad(case, dtn, conv_path):
     dt = DT[dtn]
     _, N, H, Cc, K, R, stride, pad = case
+    if conv_path.startswith("tile_alt") and Cc < 128:
+        pytest.skip("alternative tile shapes exist for >= 128 output channels only")
     Ho = (H + 2 * pad - R) // stride + 1
     w = gen(K, Cc, R, R, seed=21, scale=(2.0 / (K * R * R)) ** 0.5)
     dz = gen(N, K, Ho, Ho, seed=22)
@@ -208,13 +253,13 @@ def test_conv_dgrad(case, dtn):
     wt = D(w.permute(1, 2, 3, 0).contiguous().to(dt))     # [C][R][S][K]
     dx = torch.full((N, H, H, Cc), float("nan"), dtype=dt, device=dev())
     d = conv_desc(dt, N, Ho, Ho, H, H, Cc, R, stride, pad, 1, mk_src(dzd, K))
-    vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wt.data_ptr(), dx.data_ptr(), None, 0, 0, None, st()))
+    conv_run(d, wt, dx, plain=conv_path == "tap")
     torch.cuda.synchronize()
     got = from_nhwc(dx)
     err = (got - ref).abs().max().item()
     assert err <= tol(dt, ref), err
     # accumulate flag
-    vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wt.data_ptr(), dx.data_ptr(), None, 0, 1, None, st()))
+    conv_run(d, wt, dx, acc=1, plain=conv_path == "tap")
     torch.cuda.synchronize()
     err2 = (from_nhwc(dx) - 2 * ref).abs().max().item()
     assert err2 <= 2.5 * tol(dt, ref), err2
@@ -235,7 +280,7 @@ def test_conv_dgrad_split(dtn):
     y0 = torch.empty((N, H, H, Cup), dtype=dt, device=dev())
     y1 = torch.empty((N, H, H, Cskip), dtype=dt, device=dev())
     d = conv_desc(dt, N, H, H, H, H, Cup + Cskip, 3, 1, 1, 1, mk_src(dzd, K))
-    vk._lib.check(vk.lib().vk_conv_fwd(C.byref(d), wt.data_ptr(), y0.data_ptr(), y1.data_ptr(), Cup, 0, None, st()))
+    conv_run(d, wt, y0, y1, Cup)
     torch.cuda.synchronize()
     assert (from_nhwc(y0) - ref[:, :Cup]).abs().max().item() <= tol(dt, ref)
     assert (from_nhwc(y1) - ref[:, Cup:]).abs().max().item() <= tol(dt, ref)
@@ -259,7 +304,8 @@ def test_conv_dgrad_pool2(shape, dtn):
     y0 = torch.full((N, H // 2, H // 2, Cup), float("nan"), dtype=dt, device=dev())
     y1 = torch.full((N, H, H, max(Cskip, 8)), float("nan"), dtype=dt, device=dev()) if Cskip else None
     d = conv_desc(dt, N, H, H, H, H, Cup + Cskip, 3, 1, 1, 1, mk_src(dzd, K))
-    rc = vk.lib().vk_conv_dgrad_pool2(C.byref(d), wt.data_ptr(), y0.data_ptr(), y1.data_ptr() if Cskip else None, Cup if Cskip else 0, 0, st())
+    wp, _ = conv_w(d, wt)
+    rc = vk.lib().vk_conv_dgrad_pool2(C.byref(d), wp.data_ptr(), y0.data_ptr(), y1.data_ptr() if Cskip else None, Cup if Cskip else 0, 0, st())
     vk._lib.check(rc)
     torch.cuda.synchronize()
     t = tol(dt, ref_up) * (1.0 if dt == torch.float32 else 1.5)
@@ -295,7 +341,8 @@ def test_conv_dgrad_fused_bn_relu_reduce(dtn, pool2):
     scd, shd = D(sc), D(sh)
     bnr = L_.vk_bnr(zbd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sums.data_ptr())
     d = conv_desc(dt, N, H, H, H, H, Cc, 3, 1, 1, 1, mk_src(dzd, K))
-    vk._lib.check(vk.lib().vk_conv_dgrad_fused(C.byref(d), wt.data_ptr(), y.data_ptr(), None, 0, pool2, C.byref(bnr), st()))
+    wp, _ = conv_w(d, wt)
+    vk._lib.check(vk.lib().vk_conv_dgrad_fused(C.byref(d), wp.data_ptr(), y.data_ptr(), None, 0, pool2, C.byref(bnr), st()))
     torch.cuda.synchronize()
     got = from_nhwc(y)
     # elements whose pre-activation is within rounding of 0 may flip; compare where the mask is decided robustly

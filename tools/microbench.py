@@ -60,9 +60,18 @@ def main():
         d_d = L_.vk_conv_desc(L_.dtype_code(dt), N, H, H, H, H, Ctot, 3, 3, 1, 1, 1,
                               L_.vk_src(dz.data_ptr(), K, 0, None, None, 0), L_.vk_src(None, 0, 0, None, None, 0))
         flops = 2.0 * N * H * H * K * 9 * Ctot
+
+        def weights(d, plain, rows, red):       # halo pack when the descriptor runs on the 3x3 tile kernels
+            if not lib.vk_conv_uses_halo_pack(C.byref(d)):
+                return plain, lib.vk_conv_fwd
+            pk = torch.empty_like(plain)
+            L_.check(lib.vk_halo_pack(L_.dtype_code(dt), rows, red, plain.data_ptr(), pk.data_ptr(), st))
+            return pk, lib.vk_conv_fwd_packed
+        wf, fn_f = weights(d_f, w, K, Ctot)
+        wd_, fn_d = weights(d_d, wt, Ctot, K)
         ops = {
-            "fwd": lambda: lib.vk_conv_fwd(C.byref(d_f), w.data_ptr(), y.data_ptr(), None, 0, 0, stats.data_ptr(), st),
-            "dgrad": lambda: lib.vk_conv_fwd(C.byref(d_d), wt.data_ptr(), dx.data_ptr(), None, 0, 0, None, st),
+            "fwd": lambda: fn_f(C.byref(d_f), wf.data_ptr(), y.data_ptr(), None, 0, 0, stats.data_ptr(), st),
+            "dgrad": lambda: fn_d(C.byref(d_d), wd_.data_ptr(), dx.data_ptr(), None, 0, 0, None, st),
             "wgrad": lambda: lib.vk_conv_wgrad(C.byref(d_f), dz.data_ptr(), dw.data_ptr(), wsl.data_ptr(), wsl.numel(), st),
         }
         for op in a.ops.split(","):

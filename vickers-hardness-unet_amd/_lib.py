@@ -10,7 +10,7 @@ import subprocess
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libvkunet.so"
+LIB_PATH = Path(os.environ["VK_LIB"]) if os.environ.get("VK_LIB") else PKG_DIR / "libvkunet.so"   # VK_LIB: diagnostic builds
 CSRC = PKG_DIR / "csrc"
 
 VK_F32, VK_BF16, VK_F16 = 0, 1, 2
@@ -52,12 +52,16 @@ SIGNATURES = {
     "vk_version": (ci, []),
     "vk_last_error_string": (C.c_char_p, []),
     "vk_has_gfx950_code": (ci, []),
+    "vk_debug_set_stamp_buffer": (ci, [vp]),
     "vk_prof_enable": (ci, [ci]),
     "vk_prof_collect": (ci, [C.c_char_p, sz]),
     "vk_conv_fwd": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp, vp]),
     "vk_conv_dgrad_pool2": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp]),
     "vk_conv_dgrad_fused": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, P(vk_bnr), vp]),
     "vk_head_bwd_fused": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp, vp, P(vk_bnr), vp]),
+    "vk_halo_pack": (ci, [ci, ci, ci, vp, vp, vp]),
+    "vk_conv_uses_halo_pack": (ci, [P(vk_conv_desc)]),
+    "vk_conv_fwd_packed": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp, vp]),
     "vk_stem_fwd": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     "vk_conv_wgrad": (ci, [P(vk_conv_desc), vp, vp, vp, sz, vp]),
     "vk_stem_wgrad": (ci, [ci, ci, ci, ci, vp, vp, vp, vp]),

@@ -19,6 +19,12 @@
 
 #include "vk_common.h"
 
+#ifdef VK_STAMP
+#define VK_T(var) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); var = t_; }
+#else
+#define VK_T(var)
+#endif
+
 namespace vk {
 
 struct HaloSrc {
@@ -41,6 +47,7 @@ struct HaloParams {
   int tiles_x, tiles_y, nchunks;
   // fused BatchNorm+ReLU backward reduce on the first output part: g = y * [z*scale+shift > 0] is stored instead of y and
   // sum(g), sum(g*z) go to bnr_sums [VK_STATS_REPLICAS][2][ld0]
+  unsigned long long* stamps;   // diagnostic builds (-DVK_STAMP) only
   const void* bnr_z;
   const float* bnr_scale;
   const float* bnr_shift;
@@ -82,15 +89,16 @@ __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 //   * optional channel split (concat gradient): channels >= split go to y1
 //   * optional pool2: the FIRST output part is summed over 2x2 pixel groups and written at half resolution
 //     (nearest-x2 upsample backward fused into the data gradient; the full-resolution tensor never exists)
-template <typename T, int TH, int BN, int TP, int TC>
+template <typename T, int TH, int BN, int TP, int TC, int NT = 256>
 __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP], const HaloParams& p, int n, int y0, int x0, int n0,
                                               int wrow0, int wch0) {
   using Tr = ElemTraits<T>;
   constexpr int EB = Tr::kBytes, VE = Tr::kVec;
   constexpr int BM = TH * 16;
   constexpr int ESB = BN * EB + 16;
-  constexpr int EVPR = BN / VE, ERPP = 256 / EVPR, EPASS = BM / ERPP;
+  constexpr int EVPR = BN / VE, ERPP = NT / EVPR, EPASS = BM / ERPP, NW = NT / 64;
   constexpr int RED_OFF = BM * ESB;
+  static_assert(BM % ERPP == 0 && EVPR <= 64, "epilogue mapping");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
 #pragma unroll
@@ -211,7 +219,7 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
     if (tid < BN && n0 + tid < p.K) {
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      for (int w = 0; w < NW; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
       if (p.bnr_sums) {
         const int kc = p.ld0;          // channel count of the first output part
         if (n0 + tid < kc) {
@@ -265,22 +273,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
     h_full[i] = ok ? (n * p.H + y) * p.W + x : -1;
     h_half[i] = ok ? (n * Hh + (y >> 1)) * Wh + (x >> 1) : -1;
   }
-  // weights: element offset of this thread's vectors for filter row 0 / chunk 0; data-gradient mode walks the taps
-  // backwards (tap 8 - t) instead of flipping the halo accesses
-  int b_goff[NBV], b_loff[NBV];
+  // weights come in the "halo pack": [chunk][tap][K rows][64 B], the 16-byte pieces of a row already XOR-swizzled the way
+  // the LDS image wants them.  A stage (chunk, filter row) = three contiguous BN x 64-byte slabs -> every wave-instruction
+  // copies 1 KiB of consecutive bytes (the stamp profile showed the former [K][tap][C] gather costing as much as the MFMAs).
+  // Data-gradient mode walks the taps backwards (tap 8 - t) instead of flipping the halo accesses.
+  int b_toff[NBV];                               // byte offset of this thread's vector inside its slab, -1 = unused slot
+  int b_s[NBV];                                  // which of the three taps of the stage
 #pragma unroll
   for (int i = 0; i < NBV; ++i) {
     const int idx = tid + i * 256;
-    const int v = idx & 3;
-    const int row = (idx >> 2) % BN;
-    const int s = (idx >> 2) / BN;
-    const int nrow = n0 + row;
-    const bool ok = (idx < 3 * BN * 4) && nrow < p.K;
-    const int tap = p.flip ? 8 - s : s;
-    b_goff[i] = ok ? (nrow * 9 + tap) * p.C + v * VE : -1;
-    b_loff[i] = (s * BN + row) * 64 + ((v ^ swz(row)) << 4);
+    b_s[i] = idx / (BN * 4);
+    b_toff[i] = idx < 3 * BN * 4 ? (idx - b_s[i] * (BN * 4)) * 16 : -1;
   }
-  const int b_rowstep = (p.flip ? -3 : 3) * p.C;   // element step per filter row
+  const uint32_t slab_bytes = (uint32_t)p.K * 64u;         // one (chunk, tap) slab
 
   u32x4_t areg[NPV], breg0[NBV], breg1[NBV];   // weights are prefetched TWO filter rows ahead (two register sets)
   float sc[VE], sh[VE];
@@ -336,16 +341,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
   // weights of filter row r, chunk cc: rows n0..n0+BN, three taps
   auto load_b = [&](u32x4_t (&breg)[NBV], int stage) {
     const int cc = stage / 3, r = stage - cc * 3;
-    const int uoff = r * b_rowstep + cc * CK;      // block-uniform (taps run 8..0 in data-gradient mode)
 #pragma unroll
-    for (int i = 0; i < NBV; ++i)
-      breg[i] = buf_load16(rsw, b_goff[i] >= 0 ? (uint32_t)(b_goff[i] + uoff) * (uint32_t)EB : kOOB);
+    for (int i = 0; i < NBV; ++i) {
+      const int tap = p.flip ? 8 - (3 * r + b_s[i]) : 3 * r + b_s[i];
+      const uint32_t base = (uint32_t)(cc * 9 + tap) * slab_bytes + (uint32_t)n0 * 64u;     // block-uniform per tap
+      breg[i] = buf_load16(rsw, b_toff[i] >= 0 ? base + (uint32_t)b_toff[i] : kOOB);
+    }
   };
   auto store_b = [&](const u32x4_t (&breg)[NBV], int buf) {
     char* B = Bbuf + buf * Cfg::B_BYTES;
 #pragma unroll
     for (int i = 0; i < NBV; ++i)
-      if (tid + i * 256 < 3 * BN * 4) *reinterpret_cast<u32x4_t*>(B + b_loff[i]) = breg[i];
+      if (b_toff[i] >= 0) *reinterpret_cast<u32x4_t*>(B + b_s[i] * (BN * 64) + b_toff[i]) = breg[i];     // linear copy
   };
 
   // ---- accumulators and per-lane fragment bases (fragment reads are base + immediate)
@@ -392,6 +399,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
     __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
   };
 
+#ifdef VK_STAMP
+  unsigned long long t_begin;
+  VK_T(t_begin)
+#endif
   // ---- pipeline over (chunk, filter row) stages.  Halo: single LDS buffer, next chunk waits in registers for three
   // stages.  Weights: two LDS buffers + two register sets, i.e. the global loads of stage s+2 are issued before the
   // MFMAs of stage s and written to LDS after the MFMAs of stage s+1 (a full stage of slack for the L2/HBM latency).
@@ -403,25 +414,258 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
   if (nst > 1) load_b(breg1, 1);
   __syncthreads();
 
+#ifdef VK_STAMP
+  unsigned long long tk_load = 0, tk_comp = 0, tk_store = 0, tk_bar = 0;
+#endif
   auto stage = [&](int st, u32x4_t (&ld_regs)[NBV], const u32x4_t (&st_regs)[NBV]) {
     const int cc = st / 3, r = st - cc * 3;
     const bool next_chunk = cc + 1 < p.nchunks;
+#ifdef VK_STAMP
+    unsigned long long t0, t1, t2, t3, t4;
+#endif
+    VK_T(t0)
     if (st + 2 < nst) load_b(ld_regs, st + 2);
     if (r == 0 && next_chunk) load_halo(cc + 1);
+    VK_T(t1)
     compute(st & 1, r);
+    VK_T(t2)
     if (r == 2 && next_chunk) {
       __syncthreads();                                  // every wave is done reading this chunk's halo
       store_halo();
     }
     if (st + 1 < nst) store_b(st_regs, (st + 1) & 1);
+    VK_T(t3)
     __syncthreads();
+    VK_T(t4)
+#ifdef VK_STAMP
+    tk_load += t1 - t0; tk_comp += t2 - t1; tk_store += t3 - t2; tk_bar += t4 - t3;
+#endif
   };
   for (int st = 0; st < nst; st += 2) {
     stage(st, breg0, breg1);                            // even stage: reads B[0], stores set 1 -> B[1], loads set 0
     if (st + 1 < nst) stage(st + 1, breg1, breg0);      // odd stage : reads B[1], stores set 0 -> B[0], loads set 1
   }
 
+#ifdef VK_STAMP
+  unsigned long long te0, te1;
+  VK_T(te0)
+#endif
   halo_epilogue<T, TH, BN, TP, TC>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
+#ifdef VK_STAMP
+  VK_T(te1)
+  if (p.stamps && lane == 0) {
+    unsigned long long* o = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    o[0] = tk_load; o[1] = tk_comp; o[2] = tk_store; o[3] = tk_bar; o[4] = te1 - te0; o[5] = te0 - t_begin; o[6] = te1 - t_begin; o[7] = nst;
+  }
+#endif
+}
+
+// ---- column-staged variant (v2 main loop).  Same tile / halo / epilogue as above, different dataflow:
+//   * a stage is (channel chunk, filter COLUMN s): the wave reads its TP+2 halo rows once at column shift s and uses each of them
+//     for up to three filter rows (row h feeds output rows h, h-1, h-2) -> (TP + 2 + 3 TC) fragment reads per 3 TP TC MFMAs
+//     instead of 3 (TP + TC): 0.375 reads per MFMA at TP = TC = 4, 0.23 at TP = 8 (the row-staged loop sits at 0.5 and is
+//     LDS-bound: LDS reads + ds_write_b128 of the weights come to ~90 % of the LDS cycles at full MFMA rate).
+//   * weights never touch a VGPR: the halo pack is the LDS image, so a stage's three taps are 3 BN / 16 linear 1-KiB pieces
+//     copied by LDS-DMA (buffer_load_dwordx4 ... lds), issued one stage ahead into the other weight buffer and retired by
+//     the vmcnt(0) of the stage's closing barrier.
+//   * WGM x WGN waves (4 or 8) share one halo and one weight stream: an 8-wave 16x16x128 tile halves the per-MFMA weight
+//     traffic (L2 -> LDS) of the 4-wave 8x16x128 tile.
+//   * ADB: the halo image is double buffered (next chunk written during stage 1, no extra barrier); otherwise it is written
+//     after an extra barrier in stage 2 (less LDS -> two workgroups per CU).
+template <typename T, int TH, int BN, int WGM, int WGN, bool ADB>
+struct ColCfg {
+  using Tr = ElemTraits<T>;
+  static constexpr int EB = Tr::kBytes;
+  static constexpr int VE = Tr::kVec;
+  static constexpr int CK = 64 / EB;
+  static constexpr int NW = WGM * WGN, NT = 64 * NW;
+  static constexpr int HH = TH + 2, HPIX = HH * 18;
+  static constexpr int APS = 96;
+  static constexpr int A_BYTES = HPIX * APS;
+  static constexpr int NA = ADB ? 2 : 1;
+  static constexpr int B_BYTES = 3 * BN * 64;
+  static constexpr int NPV = (HPIX * 4 + NT - 1) / NT;
+  static constexpr int NPIECE = 3 * BN / 16;           // 1-KiB LDS-DMA pieces per stage
+  static constexpr int BM = TH * 16;
+  static constexpr int TP = TH / WGM, TC = BN / WGN / 16;
+  static constexpr int ESB = BN * EB + 16;
+  static constexpr int MAIN = NA * A_BYTES + 2 * B_BYTES;
+  static constexpr int EPI = BM * ESB + NW * BN * 2 * 4;
+  static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
+  static_assert(TH % WGM == 0 && BN % (16 * WGN) == 0 && (NW == 4 || NW == 8), "wave layout");
+};
+
+template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const HaloParams p) {
+  using Cfg = ColCfg<T, TH, BN, WGM, WGN, ADB>;
+  constexpr int EB = Cfg::EB, VE = Cfg::VE, CK = Cfg::CK, HPIX = Cfg::HPIX, NPV = Cfg::NPV, NT = Cfg::NT, NW = Cfg::NW;
+  constexpr int TP = Cfg::TP, TC = Cfg::TC, APS = Cfg::APS, NPIECE = Cfg::NPIECE;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Abuf = smem;
+  char* const Bbuf = smem + Cfg::NA * Cfg::A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int bt = blockIdx.x;
+  const int tx = bt % p.tiles_x;
+  bt /= p.tiles_x;
+  const int ty = bt % p.tiles_y;
+  const int n = bt / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const int n0 = blockIdx.y * BN;
+
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.s0.ptr, p.s0.bytes);
+  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.s1.ptr ? p.s1.ptr : p.s0.ptr, p.s1.ptr ? p.s1.bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
+
+  // ---- halo staging geometry (as in the row-staged kernel, NT threads)
+  const int hv = tid & 3;
+  int h_full[NPV], h_half[NPV];
+  const int Hh = p.H >> 1, Wh = p.W >> 1;
+#pragma unroll
+  for (int i = 0; i < NPV; ++i) {
+    const int hp = (tid >> 2) + i * (NT / 4);
+    const int hy = hp / 18, hx = hp - hy * 18;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = hp < HPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    h_full[i] = ok ? (n * p.H + y) * p.W + x : -1;
+    h_half[i] = ok ? (n * Hh + (y >> 1)) * Wh + (x >> 1) : -1;
+  }
+  u32x4_t areg[NPV];
+  float sc[VE], sh[VE];
+  bool aff = false, relu = false;
+
+  auto load_halo = [&](int cc) {
+    const int c = cc * CK;
+    const bool first = c < p.s0.C;
+    const HaloSrc& sd = first ? p.s0 : p.s1;
+    const int cl = (first ? c : c - p.s0.C) + hv * VE;
+    aff = sd.scale != nullptr;
+    relu = sd.relu != 0;
+    if (aff) {
+#pragma unroll
+      for (int j = 0; j < VE; j += 4) {
+        const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(sd.scale + cl + j);
+        const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(sd.shift + cl + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[j + e] = s4[e]; sh[j + e] = h4[e]; }
+      }
+    }
+    const bool up = sd.up != 0;
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int pix = up ? h_half[i] : h_full[i];
+      const uint32_t off = (uint32_t)(pix * sd.C + cl) * (uint32_t)EB;
+      if (first) areg[i] = buf_load16(rs0, pix >= 0 ? off : kOOB);
+      else areg[i] = buf_load16(rs1, pix >= 0 ? off : kOOB);
+    }
+  };
+  auto store_halo = [&](char* A) {
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int hp = (tid >> 2) + i * (NT / 4);
+      if (hp >= HPIX) continue;
+      u32x4_t v = areg[i];
+      if (aff) {
+        float f[VE];
+        Vec16<T>::unpack(v, f);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+          f[j] = fmaf(f[j], sc[j], sh[j]);
+          if (relu) f[j] = fmaxf(f[j], 0.f);
+        }
+        v = Vec16<T>::pack(f);
+        if (h_full[i] < 0) v = u32x4_t{0, 0, 0, 0};     // zero padding is applied after BN+ReLU
+      }
+      *reinterpret_cast<u32x4_t*>(A + hp * APS + hv * 16) = v;
+    }
+  };
+
+  // weights of stage (chunk cc, filter column s) -> weight buffer `buf`: slot r = tap (r, s); data-gradient mode takes tap 8 - t
+  const uint32_t slab_bytes = (uint32_t)p.K * 64u;         // one (chunk, tap) slab of the halo pack
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto dma_b = [&](int cc, int s, int buf) {
+#pragma unroll
+    for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
+      const int pc = wave + i * NW;                        // wave-uniform
+      if (NPIECE % NW == 0 || pc < NPIECE) {
+        const int r = pc / (BN / 16), sub = pc - r * (BN / 16);
+        const int tap = p.flip ? 8 - (3 * r + s) : 3 * r + s;
+        const uint32_t goff = (uint32_t)(cc * 9 + tap) * slab_bytes + (uint32_t)(n0 + sub * 16) * 64u;
+        char* dst = Bbuf + buf * Cfg::B_BYTES + (r * BN + sub * 16) * 64;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, lane16, goff, 0, 0);
+      }
+    }
+  };
+
+  // ---- accumulators and per-lane fragment bases
+  const int wrow0 = (wave / WGN) * TP;
+  const int wch0 = (wave % WGN) * (TC * 16);
+  f32x4_t acc[TC][TP];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int li = lane & 15, kg = lane >> 4;
+  const int a_lane = (wrow0 * 18 + li) * APS + kg * 16;
+  const int b_lane = (wch0 + li) * 64 + ((kg ^ swz(li)) << 4);
+
+  auto compute = [&](const char* A, const char* B) {
+    u32x4_t X[TP + 2], W[3][TC];
+#pragma unroll
+    for (int h = 0; h < TP + 2; ++h) X[h] = *reinterpret_cast<const u32x4_t*>(A + h * (18 * APS));
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int a = 0; a < TC; ++a) W[r][a] = *reinterpret_cast<const u32x4_t*>(B + (r * BN + a * 16) * 64);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = Mma<T>::run(W[r][a], X[b + r], acc[a][b]);
+    // issue order: [halo rows + filter row 0][filter row 1][MFMAs row 0][filter row 2][MFMAs row 1][MFMAs row 2]
+    constexpr int NM = TC * TP * (sizeof(T) == 4 ? 4 : 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, TP + 2 + TC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, TC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, TC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+  };
+
+  // ---- prologue: chunk 0 halo + stage 0 weights
+  load_halo(0);
+  dma_b(0, 0, 0);
+  store_halo(Abuf);
+  __syncthreads();                                        // also drains the LDS-DMA (vmcnt(0))
+
+  int st = 0;
+  for (int cc = 0; cc < p.nchunks; ++cc) {
+    const bool next_chunk = cc + 1 < p.nchunks;
+    const char* A = Abuf + (ADB ? (cc & 1) * Cfg::A_BYTES : 0) + a_lane;
+    char* const Anext = Abuf + (ADB ? ((cc + 1) & 1) * Cfg::A_BYTES : 0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s, ++st) {
+      // next stage's weights into the other buffer (all waves passed the barrier that closed its last readers)
+      if (s < 2) dma_b(cc, s + 1, (st + 1) & 1);
+      else if (next_chunk) dma_b(cc + 1, 0, (st + 1) & 1);
+      if (s == 0 && next_chunk) load_halo(cc + 1);
+      compute(A + s * APS, Bbuf + (st & 1) * Cfg::B_BYTES + b_lane);
+      if (ADB) {
+        if (s == 1 && next_chunk) store_halo(Anext);
+      } else {
+        if (s == 2 && next_chunk) {
+          __syncthreads();                                // every wave is done reading this chunk's halo
+          store_halo(Anext);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  halo_epilogue<T, TH, BN, TP, TC, NT>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
 }
 
 // ---- C == 16 (16-bit types): decoder block 4 conv2 and the data gradients whose reduction runs over 16 channels.
@@ -552,6 +796,42 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const HaloParams p) {
   halo_epilogue<T, TH, BN, TP, TC>(smem, acc, p, n, y0, x0, n0, wrow0, 0);
 }
 
+// ---- weight repack into the halo layout.  src: [rows][9][red] of T (rows = output channels of the GEMM: K for forward
+// weights [K][3][3][C], C for the transposed data-gradient weights [C][3][3][K]; red = reduction channels).
+// dst: [red / CK][9][rows][CK] with the four 16-byte pieces of every 64-byte row stored at piece ^ (((row >> 2) & 1) << 1).
+template <typename T>
+__global__ void k_pack_halo(int rows, int red, const T* __restrict__ src, T* __restrict__ dst) {
+  constexpr int CK = 64 / ElemTraits<T>::kBytes, VE = ElemTraits<T>::kVec;
+  const size_t total = (size_t)rows * 9 * red / VE;            // 16-byte vectors
+  for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total; v += (size_t)gridDim.x * blockDim.x) {
+    // enumerate destination vectors: ((cc*9 + tap)*rows + k)*4 + pos
+    const int pos = (int)(v & 3);
+    size_t t = v >> 2;
+    const int k = (int)(t % rows);
+    t /= rows;
+    const int tap = (int)(t % 9);
+    const int cc = (int)(t / 9);
+    const int j = pos ^ (((k >> 2) & 1) << 1);
+    const u32x4_t x = *reinterpret_cast<const u32x4_t*>(src + ((size_t)k * 9 + tap) * red + cc * CK + j * VE);
+    *reinterpret_cast<u32x4_t*>(dst + v * VE) = x;
+  }
+}
+
+int halo_pack_impl(vk_dtype dt, int rows, int red, const void* src, void* dst, hipStream_t st) {
+  const int eb = dt == VK_F32 ? 4 : 2;
+  VK_CHECK_ARG(src && dst && rows > 0 && red % (64 / eb) == 0, "vk_halo_pack: reduction channels %d must be a multiple of %d", red, 64 / eb);
+  const size_t nvec = (size_t)rows * 9 * red * eb / 16;
+  unsigned nb = (unsigned)((nvec + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  switch (dt) {
+    case VK_F32: hipLaunchKernelGGL(k_pack_halo<float>, dim3(nb), dim3(256), 0, st, rows, red, (const float*)src, (float*)dst); break;
+    case VK_BF16: hipLaunchKernelGGL(k_pack_halo<bf16_t>, dim3(nb), dim3(256), 0, st, rows, red, (const bf16_t*)src, (bf16_t*)dst); break;
+    case VK_F16: hipLaunchKernelGGL(k_pack_halo<f16_t>, dim3(nb), dim3(256), 0, st, rows, red, (const f16_t*)src, (f16_t*)dst); break;
+  }
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ host
 template <typename T, int TH, int BN, int WGM, int WGN>
 static int launch_halo(HaloParams p, hipStream_t st) {
@@ -579,8 +859,55 @@ static int launch_halo(HaloParams p, hipStream_t st) {
   return VK_OK;
 }
 
+template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW>
+static int launch_col(HaloParams p, hipStream_t st) {
+  using Cfg = ColCfg<T, TH, BN, WGM, WGN, ADB>;
+  p.tiles_x = (p.W + 15) / 16;
+  p.tiles_y = (p.H + TH - 1) / TH;
+  dim3 grid((unsigned)(p.N * p.tiles_y * p.tiles_x), (unsigned)((p.K + BN - 1) / BN), 1);
+  static bool attr_done = false;
+  if (!attr_done && Cfg::SMEM > 64 * 1024) {
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_col_kernel<T, TH, BN, WGM, WGN, ADB, MINW>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+    attr_done = true;
+  }
+  {
+    static const std::string tag_f = std::string("col_") + (sizeof(T) == 4 ? "f32" : "16b") + "_t" + std::to_string(TH) + "_bn" + std::to_string(BN) +
+                                     "_w" + std::to_string(WGM * WGN);
+    static const std::string tag_d = tag_f + "_dgrad";
+    const double macs = (double)p.N * p.H * p.W * p.K * 9.0 * p.C;
+    const double bytes = ((double)p.N * p.H * p.W * (p.C + p.K) + 9.0 * p.K * p.C) * sizeof(T);
+    const std::string& btag = p.flip ? tag_d : tag_f;
+    const std::string dtag = getenv("VK_PROF_DETAIL") ? btag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) : btag;
+    vkh::ProfScope ps(dtag.c_str(), st, 2.0 * macs, bytes);
+    hipLaunchKernelGGL((conv3x3_col_kernel<T, TH, BN, WGM, WGN, ADB, MINW>), grid, dim3(Cfg::NT), Cfg::SMEM, st, p);
+  }
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+// tile selection for the column-staged kernels.  VK_COL_ALT (diagnostic / tests) forces a shape of the K >= 128 class:
+//   1: 4 waves, 16x16x128, 8 rows x 64 channels per wave (one wave per SIMD);  2: the 8-wave 16x16x128 tile;  3: the 4-wave 8x16x128 tile
+template <typename T>
+static int col_select(const HaloParams& p, hipStream_t st) {
+  const char* alt_s = getenv("VK_COL_ALT");
+  const int alt = alt_s ? atoi(alt_s) : 0;
+  const long tiles16 = (long)p.N * ((p.H + 15) / 16) * ((p.W + 15) / 16);
+  if (p.K >= 128) {
+    const long kt = (p.K + 127) / 128;
+    if (alt == 1) return launch_col<T, 16, 128, 2, 2, true, 1>(p, st);
+    if (alt == 3 || (alt != 2 && tiles16 * kt < 256)) return launch_col<T, 8, 128, 2, 2, false, 2>(p, st);
+    return launch_col<T, 16, 128, 4, 2, true, 2>(p, st);                    // 8 waves, 4 rows x 64 channels per wave
+  }
+  if (p.K >= 64) return launch_col<T, 16, 64, 4, 1, false, 2>(p, st);
+  if (p.K >= 32) return launch_col<T, 16, 32, 4, 1, false, 2>(p, st);
+  return launch_col<T, 16, 16, 4, 1, false, 2>(p, st);
+}
+
 template <typename T>
 static int halo_select(const HaloParams& p, hipStream_t st) {
+  static const bool old_loop = getenv("VK_HALO_ROWSTAGED") != nullptr;      // diagnostic: the v1 row-staged main loop
+  if (!old_loop) return col_select<T>(p, st);
   const long tiles8 = (long)p.N * ((p.H + 7) / 8) * ((p.W + 15) / 16);
   const long tiles16 = (long)p.N * ((p.H + 15) / 16) * ((p.W + 15) / 16);
   if (p.K >= 128) {
@@ -614,13 +941,15 @@ static int launch_c16(HaloParams p, hipStream_t st) {
 }
 
 // returns VK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the tap-by-tap kernel)
-int conv3x3_halo_try(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate, double* stats,
+// w: halo pack (vk_halo_pack) when `packed`, plain [K][3][3][C] otherwise — only the C == 16 kernel takes the plain layout
+int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, void* y1, int split_k1, int accumulate, double* stats,
                      int pool2, const vk_bnr* bnr, hipStream_t st) {
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->H != d->Ho || d->W != d->Wo) return VK_ERR_UNSUPPORTED;
   const int eb = d->dtype == VK_F32 ? 4 : 2;
   const int ck = 64 / eb;
   const int C = d->src0.C + (d->src1.ptr ? d->src1.C : 0);
   const bool c16 = (eb == 2) && C == 16 && !d->src1.ptr && !d->src0.up;
+  if (c16 ? packed : !packed) return VK_ERR_UNSUPPORTED;
   if (!c16 && (d->src0.C % ck || (d->src1.ptr && d->src1.C % ck))) return VK_ERR_UNSUPPORTED;
   if (d->K % 16) return VK_ERR_UNSUPPORTED;
   if (pool2 && ((d->H | d->W) & 1)) return VK_ERR_UNSUPPORTED;
@@ -646,6 +975,10 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, void* y, void* y1, in
   p.flip = d->transposed;
   p.accumulate = accumulate;
   p.pool2 = pool2;
+  p.stamps = nullptr;
+#ifdef VK_STAMP
+  { extern unsigned long long* g_vk_stamp_buf; p.stamps = g_vk_stamp_buf; }
+#endif
   p.bnr_z = bnr ? bnr->z : nullptr;
   p.bnr_scale = bnr ? bnr->scale : nullptr;
   p.bnr_shift = bnr ? bnr->shift : nullptr;

@@ -469,15 +469,20 @@ static int dispatch(vk_dtype dt, const ConvParams& p, int mode, hipStream_t st) 
   return VK_ERR_ARG;
 }
 
-int conv3x3_halo_try(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate, double* stats,
+int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, void* y1, int split_k1, int accumulate, double* stats,
                      int pool2, const vk_bnr* bnr, hipStream_t st);
+int halo_pack_impl(vk_dtype dt, int rows, int red, const void* src, void* dst, hipStream_t st);
+
+static bool is_c16(const vk_conv_desc* d) {
+  return d->dtype != VK_F32 && d->src0.C == 16 && !d->src1.ptr && !d->src0.up;
+}
 
 static bool halo_enabled() {
   static const bool on = getenv("VK_NO_HALO") == nullptr;
   return on;
 }
 
-int conv_fwd_impl(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate,
+int conv_fwd_impl(const vk_conv_desc* d, const void* w, int packed, void* y, void* y1, int split_k1, int accumulate,
                   double* stats, int pool2, const vk_bnr* bnr, hipStream_t st) {
   VK_CHECK_ARG(d && w && y, "vk_conv_fwd: null argument");
   const int eb = d->dtype == VK_F32 ? 4 : 2;
@@ -498,8 +503,12 @@ int conv_fwd_impl(const vk_conv_desc* d, const void* w, void* y, void* y1, int s
   VK_CHECK_ARG(!(d->src1.ptr && d->src1.up), "vk_conv_fwd: only src0 may be upsampled");
   if (halo_enabled() && (!d->transposed || d->stride == 1)) {
     // 3x3 stride-1 convolutions (and their data gradients) go to the LDS-staged halo kernel
-    const int rc = conv3x3_halo_try(d, w, y, y1, split_k1, accumulate, stats, pool2, bnr, st);
+    const int rc = conv3x3_halo_try(d, w, packed, y, y1, split_k1, accumulate, stats, pool2, bnr, st);
     if (rc != VK_ERR_UNSUPPORTED) return rc;
+  }
+  if (packed) {
+    vkh::set_error("vk_conv_fwd_packed: shape not covered by the 3x3 stride-1 tile kernels (use vk_conv_fwd with plain weights)");
+    return VK_ERR_UNSUPPORTED;
   }
   if (pool2 || bnr) {
     vkh::set_error("vk_conv_dgrad_fused: pooled / BN-fused outputs are only available on the 3x3 stride-1 tile kernels");
@@ -570,18 +579,37 @@ int stem_fwd_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void* 
 
 extern "C" int vk_conv_fwd(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int accumulate,
                            double* stats, void* stream) {
-  return vk::conv_fwd_impl(d, w, y, y1, split_k1, accumulate, stats, 0, nullptr, (hipStream_t)stream);
+  return vk::conv_fwd_impl(d, w, 0, y, y1, split_k1, accumulate, stats, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int vk_conv_dgrad_pool2(const vk_conv_desc* d, const void* w, void* y_half, void* y1, int split_k1, int accumulate,
                                    void* stream) {
-  return vk::conv_fwd_impl(d, w, y_half, y1, split_k1, accumulate, nullptr, 1, nullptr, (hipStream_t)stream);
+  return vk::conv_fwd_impl(d, w, vk::is_c16(d) ? 0 : 1, y_half, y1, split_k1, accumulate, nullptr, 1, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int vk_conv_dgrad_fused(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int pool2, const vk_bnr* bnr,
                                    void* stream) {
   VK_CHECK_ARG(!bnr || (bnr->z && bnr->scale && bnr->shift && bnr->sums), "vk_conv_dgrad_fused: incomplete vk_bnr");
-  return vk::conv_fwd_impl(d, w, y, y1, split_k1, 0, nullptr, pool2, bnr, (hipStream_t)stream);
+  return vk::conv_fwd_impl(d, w, vk::is_c16(d) ? 0 : 1, y, y1, split_k1, 0, nullptr, pool2, bnr, (hipStream_t)stream);
+}
+
+extern "C" int vk_conv_fwd_packed(const vk_conv_desc* d, const void* w_halo, void* y, void* y1, int split_k1, int accumulate, double* stats,
+                                  void* stream) {
+  return vk::conv_fwd_impl(d, w_halo, 1, y, y1, split_k1, accumulate, stats, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int vk_halo_pack(vk_dtype dtype, int rows, int red, const void* src, void* dst, void* stream) {
+  return vk::halo_pack_impl(dtype, rows, red, src, dst, (hipStream_t)stream);
+}
+
+extern "C" int vk_conv_uses_halo_pack(const vk_conv_desc* d) {
+  if (!d || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->H != d->Ho || d->W != d->Wo) return 0;
+  if (vk::is_c16(d)) return 0;
+  const int ck = d->dtype == VK_F32 ? 16 : 32;
+  if (d->src0.C % ck || (d->src1.ptr && (d->src1.C % ck || d->src1.up)) || d->K % 16) return 0;
+  const size_t C = (size_t)d->src0.C + (d->src1.ptr ? d->src1.C : 0), px = (size_t)d->N * d->H * d->W;
+  if (px * C * (d->dtype == VK_F32 ? 4 : 2) >= (1ull << 31) || px >= (1ull << 31)) return 0;
+  return getenv("VK_NO_HALO") ? 0 : 1;
 }
 
 extern "C" int vk_stem_fwd(vk_dtype dtype, int N, int H, int W, const void* x4, const void* wp, void* y,

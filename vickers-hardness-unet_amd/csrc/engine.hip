@@ -92,6 +92,14 @@ extern "C" int vk_version(void) { return VK_ABI_VERSION; }
 extern "C" const char* vk_last_error_string(void) { return vkh::g_err; }
 
 namespace vk {
+unsigned long long* g_vk_stamp_buf = nullptr;     // diagnostic (-DVK_STAMP) builds: per-wave cycle stamps of the tile kernels
+}
+extern "C" int vk_debug_set_stamp_buffer(void* p) {
+  vk::g_vk_stamp_buf = (unsigned long long*)p;
+  return VK_OK;
+}
+
+namespace vk {
 
 __global__ void k_probe() {}
 
@@ -126,6 +134,50 @@ __global__ __launch_bounds__(256) void k_pack_dgrad(const PackEntry* __restrict_
       if (k < e.K && c < e.C) st1(arena + e.dst + ((int64_t)c * e.RS + t) * e.K + k, tl[tx][ty + 8 * i]);
     }
     __syncthreads();
+  }
+}
+
+// halo pack of one 3x3 layer straight from the fp32 master weights [K][9][C] (layout: vk_halo_pack in vk_unet.h).
+//   transposed == 0: forward weights, rows = K, reduction = C
+//   transposed == 1: data-gradient weights (row = input channel c, reduction over k): element (c, tap, k) = params[(k*9 + tap)*C + c]
+struct HaloPackEntry {
+  int64_t src;          // element offset in the flat parameters
+  int64_t dst;          // byte offset in the workspace
+  int rows, red, transposed, pad_;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_halo_tab(const HaloPackEntry* __restrict__ tab, const float* __restrict__ params, char* __restrict__ ws) {
+  constexpr int VE = ElemTraits<T>::kVec, CK = 64 / ElemTraits<T>::kBytes;
+  const HaloPackEntry e = tab[blockIdx.y];
+  const float* src = params + e.src;
+  u32x4_t* dst = reinterpret_cast<u32x4_t*>(ws + e.dst);
+  const int rows = e.rows, red = e.red;
+  const long total = (long)rows * 9 * red / VE;
+  for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+    int pos, k, tap, cc;
+    if (!e.transposed) {            // consecutive threads -> consecutive reduction channels (contiguous in params)
+      pos = (int)(v & 3);
+      long t = v >> 2;
+      k = (int)(t % rows); t /= rows;
+      tap = (int)(t % 9); cc = (int)(t / 9);
+    } else {                        // consecutive threads -> consecutive rows (contiguous in params)
+      k = (int)(v % rows);
+      long t = v / rows;
+      pos = (int)(t & 3); t >>= 2;
+      tap = (int)(t % 9); cc = (int)(t / 9);
+    }
+    const int j = pos ^ (((k >> 2) & 1) << 1);
+    const int r0 = cc * CK + j * VE;
+    float f[VE];
+    if (!e.transposed) {
+#pragma unroll
+      for (int i = 0; i < VE; ++i) f[i] = src[((long)k * 9 + tap) * red + r0 + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < VE; ++i) f[i] = src[((long)(r0 + i) * 9 + tap) * rows + k];
+    }
+    dst[(((long)cc * 9 + tap) * rows + k) * 4 + pos] = Vec16<T>::pack(f);
   }
 }
 
@@ -171,6 +223,8 @@ struct ConvL {
   int Cin, K, R, stride, pad;
   int64_t w_off;          // flat params (KRSC)
   int64_t wd_off;         // dgrad arena offset (-1: none)
+  bool halo_fwd = false;  // forward runs on the 3x3 tile kernels and reads the halo pack of its weights
+  bool halo_dg = false;   // same for the data gradient (the dgrad arena slot then holds the pack instead of plain [C][RS][K])
   int bn;                 // following BN (-1 for the head)
   int Hin, Hout;          // square spatial sizes
   // workspace
@@ -237,7 +291,8 @@ struct vk_unet {
   size_t ws_bytes = 0;
   size_t off_x4 = 0, off_pool = 0, off_argmax = 0, off_gpool = 0, off_dup = 0, off_dlogits = 0, off_loss_sums = 0;
   size_t off_stats = 0, off_bsums = 0, stats_bytes = 0, off_farena = 0, farena_floats = 0, off_wf = 0, off_wd = 0, off_wstem = 0;
-  size_t off_tab_pack = 0, off_tab_bn = 0, off_wslab = 0;
+  size_t off_tab_pack = 0, off_tab_bn = 0, off_wslab = 0, off_wh = 0, off_tab_halo = 0;
+  std::vector<HaloPackEntry> halo_tab;
   std::vector<size_t> off_z, off_g, off_out, off_gout;
   std::vector<char> g_prereduced;      // per conv: its gradient buffer already holds masked g + sums (vk_bnr fusion)
   // bound pointers
@@ -449,6 +504,8 @@ void layout_workspace(vk_unet* h) {
   h->off_farena = take(fl * sizeof(float));
   h->off_wf = (eb == 4) ? 0 : take((size_t)h->n_params * eb);
   h->off_wd = tr ? take((size_t)h->n_dgrad * eb) : 0;
+  h->off_wh = take((size_t)h->n_params * eb);                  // halo packs of the forward weights (same offsets as the flat copy)
+  h->off_tab_halo = take(2 * h->convs.size() * sizeof(HaloPackEntry));
   h->off_wstem = take(64 * 7 * 32 * eb);
   h->off_wslab = tr ? take(VK_WGRAD_WORKSPACE_BYTES) : 0;
   h->off_tab_pack = take(h->convs.size() * sizeof(PackEntry));
@@ -503,6 +560,7 @@ void assign_pointers(vk_unet* h) {
 }
 
 const void* fwd_weights(const vk_unet* h, const ConvL& c) {
+  if (c.halo_fwd) return h->ws + h->off_wh + (size_t)c.w_off * h->eb;
   if (h->eb == 4) return h->params + c.w_off;
   return h->ws + h->off_wf + (size_t)c.w_off * h->eb;
 }
@@ -548,7 +606,8 @@ int finalize_bn(vk_unet* h, BnL& b, int training, hipStream_t st) {
 int run_conv(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, int training, hipStream_t st) {
   vk_conv_desc d = conv_desc(h, c, s0, s1);
   BnL& b = h->bns[c.bn];
-  RET_IF(vk_conv_fwd(&d, fwd_weights(h, c), c.z, nullptr, 0, 0, training ? b.stats : nullptr, st));
+  if (c.halo_fwd) RET_IF(vk_conv_fwd_packed(&d, fwd_weights(h, c), c.z, nullptr, 0, 0, training ? b.stats : nullptr, st));
+  else RET_IF(vk_conv_fwd(&d, fwd_weights(h, c), c.z, nullptr, 0, 0, training ? b.stats : nullptr, st));
   return finalize_bn(h, b, training, st);
 }
 
@@ -601,10 +660,53 @@ extern "C" int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_b
   h->params = params; h->grads = grads; h->bufs = bn_buffers; h->nbt = nbt; h->ws = (char*)workspace;
   assign_pointers(h);
   // device tables
+  // which layers run on the 3x3 tile kernels (halo pack weights): ask the kernels' own predicate with the real descriptors
+  h->halo_tab.clear();
+  {
+    auto plain = [&](int C) { vk_src s = null_src(); s.ptr = h->ws; s.C = C; return s; };
+    auto fwd_uses = [&](ConvL& c, int C0, int C1, int up) {
+      vk_src s0 = plain(C0), s1 = C1 ? plain(C1) : null_src();
+      s0.up = up;
+      vk_conv_desc d = conv_desc(h, c, s0, s1);
+      return vk_conv_uses_halo_pack(&d) != 0;
+    };
+    for (size_t i = 0; i < h->convs.size(); ++i) {
+      ConvL& c = h->convs[i];
+      c.halo_fwd = c.halo_dg = false;
+      if ((int)i == h->stem_conv || (int)i == h->head_conv) continue;
+      c.halo_fwd = fwd_uses(c, c.Cin, 0, 0);
+    }
+    for (DecL& d : h->decs) {          // decoder conv1: upsampled + skip operand
+      ConvL& c = h->convs[d.conv1];
+      c.halo_fwd = fwd_uses(c, d.Cup, d.Cskip, 1);
+    }
+    for (size_t i = 0; i < h->convs.size(); ++i) {
+      ConvL& c = h->convs[i];
+      if (c.wd_off >= 0 && h->cfg.training) {
+        vk_conv_desc d;
+        d.dtype = h->cfg.dtype;
+        d.N = h->cfg.N; d.H = c.Hout; d.W = c.Hout; d.Ho = c.Hin; d.Wo = c.Hin;
+        d.K = c.Cin; d.R = c.R; d.S = c.R; d.stride = c.stride; d.pad = c.pad; d.transposed = 1;
+        d.src0 = plain(c.K);
+        d.src1 = null_src();
+        c.halo_dg = vk_conv_uses_halo_pack(&d) != 0;
+      }
+      HaloPackEntry e;
+      e.src = c.w_off; e.pad_ = 0;
+      if (c.halo_fwd) {
+        e.dst = (int64_t)(h->off_wh + (size_t)c.w_off * h->eb); e.rows = c.K; e.red = c.Cin; e.transposed = 0;
+        h->halo_tab.push_back(e);
+      }
+      if (c.halo_dg) {
+        e.dst = (int64_t)(h->off_wd + (size_t)c.wd_off * h->eb); e.rows = c.Cin; e.red = c.K; e.transposed = 1;
+        h->halo_tab.push_back(e);
+      }
+    }
+  }
   h->pack_tab.clear();
   for (size_t i = 0; i < h->convs.size(); ++i) {
     const ConvL& c = h->convs[i];
-    if (c.wd_off < 0) continue;
+    if (c.wd_off < 0 || c.halo_dg) continue;
     PackEntry e;
     e.src = c.w_off; e.dst = c.wd_off; e.K = c.K; e.RS = c.R * c.R; e.C = c.Cin; e.pad_ = 0;
     h->pack_tab.push_back(e);
@@ -615,7 +717,10 @@ extern "C" int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_b
     e.g_off = b.g_off; e.b_off = b.b_off; e.rm_off = b.rm_off; e.rv_off = b.rv_off; e.out_off = b.arena_off; e.C = b.C; e.pad_ = 0;
     h->bn_tab.push_back(e);
   }
-  VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_pack, h->pack_tab.data(), h->pack_tab.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
+  if (!h->pack_tab.empty())
+    VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_pack, h->pack_tab.data(), h->pack_tab.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
+  if (!h->halo_tab.empty())
+    VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_halo, h->halo_tab.data(), h->halo_tab.size() * sizeof(HaloPackEntry), hipMemcpyHostToDevice));
   VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_bn, h->bn_tab.data(), h->bn_tab.size() * sizeof(BnEvalEntry), hipMemcpyHostToDevice));
   h->bound = true;
   return VK_OK;
@@ -628,6 +733,9 @@ static int refresh_t(vk_unet* h, hipStream_t st) {
   if (h->cfg.training && !h->pack_tab.empty())
     hipLaunchKernelGGL(k_pack_dgrad<T>, dim3(64, (unsigned)h->pack_tab.size()), dim3(256), 0, st,
                        (const PackEntry*)(h->ws + h->off_tab_pack), h->params, (T*)(h->ws + h->off_wd));
+  if (!h->halo_tab.empty())
+    hipLaunchKernelGGL(k_pack_halo_tab<T>, dim3(32, (unsigned)h->halo_tab.size()), dim3(256), 0, st,
+                       (const HaloPackEntry*)(h->ws + h->off_tab_halo), h->params, h->ws);
   hipLaunchKernelGGL(k_pack_stem<T>, dim3((64 * 7 * 32 + 255) / 256), dim3(256), 0, st,
                      h->params + h->convs[h->stem_conv].w_off, (T*)(h->ws + h->off_wstem));
   VK_CHECK_HIP(hipGetLastError());
@@ -781,6 +889,7 @@ int conv_dgrad_into(vk_unet* h, ConvL& c, ConvL& into, bool* fused, hipStream_t 
   int rc = getenv("VK_NO_BNR_FUSION") ? VK_ERR_UNSUPPORTED : vk_conv_dgrad_fused(&d, dgrad_weights(h, c), into.g, nullptr, 0, 0, &r, st);
   *fused = rc == VK_OK;
   if (rc != VK_ERR_UNSUPPORTED) return rc;
+  if (c.halo_dg) return vk_conv_fwd_packed(&d, dgrad_weights(h, c), into.g, nullptr, 0, 0, nullptr, st);
   return vk_conv_fwd(&d, dgrad_weights(h, c), into.g, nullptr, 0, 0, nullptr, st);
 }
 
@@ -794,6 +903,7 @@ int conv_dgrad(vk_unet* h, ConvL& c, void* y, void* y1, int split, int accumulat
   s.ptr = c.g; s.C = c.K; s.up = 0; s.scale = nullptr; s.shift = nullptr; s.relu = 0;
   d.src0 = s;
   d.src1 = null_src();
+  if (c.halo_dg) return vk_conv_fwd_packed(&d, dgrad_weights(h, c), y, y1, split, accumulate, nullptr, st);
   return vk_conv_fwd(&d, dgrad_weights(h, c), y, y1, split, accumulate, nullptr, st);
 }
 
