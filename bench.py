@@ -144,7 +144,7 @@ def main():
             dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
             tag, r = dom
             per_launch_ms = r["ms"] / r["n"]
-            if r["flops"] > 0 and any(k in tag for k in ("igemm", "wgrad", "stem", "halo")):
+            if r["flops"] > 0 and any(k in tag for k in ("igemm", "wgrad", "stem", "halo", "col_")):
                 peak = PEAK_MFMA_F32 if "f32" in tag else PEAK_MFMA_16B
                 ach = r["flops"] / (r["ms"] * 1e-3)
                 roof = {"kernel": tag, "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",

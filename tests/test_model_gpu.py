@@ -62,14 +62,56 @@ def test_eval_logits_fp32(pair, n, s):
     assert abs(vk.iou_coef(pg.to(dev()), y.to(dev())) - O.iou_coef(pg, y)) <= 1e-6
 
 
+def _engine_relu_masks(ref, model, n, s):
+    """The ReLU decisions the engine took in its last training forward, keyed by the oracle's nn.ReLU module name, in call
+    order (a BasicBlock calls its ReLU twice: after bn1 and on the block tail).  Bool NCHW CPU tensors."""
+    plan = model.plan_for(n, s, torch.float32, True)
+
+    def bn_mask(conv, bn):
+        z = plan.debug_tensor("z:" + conv).double().cpu().permute(0, 3, 1, 2)
+        sc = plan.debug_tensor("scale:" + bn).double().cpu().view(1, -1, 1, 1)
+        sh = plan.debug_tensor("shift:" + bn).double().cpu().view(1, -1, 1, 1)
+        return (z * sc + sh) > 0          # exact in fp64, so this is the sign the kernels' fmaf(z, scale, shift) sees
+
+    out = {}
+    for name, mod in ref.named_modules():
+        if not isinstance(mod, torch.nn.ReLU):
+            continue
+        if name == "encoder.relu":
+            out[name] = [bn_mask("encoder.conv1", "encoder.bn1")]
+        elif name.startswith("encoder.layer"):
+            blk = name[:-len(".relu")]
+            out[name] = [bn_mask(blk + ".conv1", blk + ".bn1"),
+                         plan.debug_tensor("out:" + blk).float().cpu().permute(0, 3, 1, 2) > 0]
+        else:                             # decoder.blocks.i.convJ.2
+            pre = name[:-1]
+            out[name] = [bn_mask(pre + "0", pre + "1")]
+    return out
+
+
 def test_train_forward_backward_fp32(pair):
-    """train-mode logits, loss, every parameter gradient and the BN running statistics."""
+    """train-mode logits, loss, every parameter gradient and the BN running statistics.
+
+    A pre-activation that is zero to within fp32 accumulation noise falls on either side of the ReLU in two correct
+    implementations (16 seeds tried: 15 had at least one such disagreement with the oracle, with the tap-by-tap, row-staged
+    and column-staged kernels alike); the forward value does not care, but at N=2 one flipped mask in a deep layer changes a
+    whole BatchNorm channel's backward sums and every upstream gradient by several percent.  So the gradient bar has two parts:
+      * against the plain oracle: 10 % L2 per parameter, and the masks may differ on at most 1e-4 of the activations;
+      * against the oracle run with the ENGINE's ReLU decisions (same weights, same arithmetic, only the discrete choice is
+        taken from the engine): max-abs error <= 1e-2 of the gradient's max for every one of the 140 parameters."""
     O, _, _ = pair
+    z = np.load(GOLDEN / "oracle_small.npz")
     O.set_seed(42); ref = O.build_model()
     O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
     x, y = O.synthetic_batch(2, 64, seed=1234)
     ref.train(); model.train()
+    ref_masks, hooks = {}, []
+    for name, mod in ref.named_modules():
+        if isinstance(mod, torch.nn.ReLU):
+            hooks.append(mod.register_forward_hook(lambda m, i, o, name=name: ref_masks.setdefault(name, []).append((o > 0).clone())))
     lo = ref(x)
+    for h in hooks:
+        h.remove()
     loss_o = O.total_loss(lo, y)
     loss_o.backward()
     lg = model(x.to(dev()))
@@ -77,27 +119,44 @@ def test_train_forward_backward_fp32(pair):
     loss_g.backward()
     torch.cuda.synchronize()
     assert (lg.detach().cpu() - lo.detach()).abs().max().item() <= 1e-3
-    z = np.load(GOLDEN / "oracle_small.npz")
     assert np.abs(lg.detach().cpu().numpy() - z["logits_train"]).max() <= 1e-3
     assert loss_g.item() == pytest.approx(loss_o.item(), rel=1e-4)
+    eng_masks = _engine_relu_masks(ref, model, 2, 64)
+    assert set(eng_masks) == set(ref_masks)
+    differ = sum(int((a != b).sum()) for k in ref_masks for a, b in zip(ref_masks[k], eng_masks[k]))
+    total = sum(a.numel() for k in ref_masks for a in ref_masks[k])
+    assert differ <= 1e-4 * total, f"{differ} of {total} ReLU decisions differ from the oracle's"
     named_o = dict(ref.named_parameters())
-    worst = 0.0
-    for k, p in model.named_parameters():
-        go, gg = named_o[k].grad, p.grad.cpu()
+    grads_g = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    for k, gg in grads_g.items():
+        go = named_o[k].grad
         assert gg.shape == go.shape, k
-        rel = (gg - go).abs().max().item() / (go.abs().max().item() + 1e-12)
-        worst = max(worst, rel)
-        assert rel <= 2e-2, f"{k}: rel grad err {rel}"
+        l2 = ((gg - go).norm() / (go.norm() + 1e-12)).item()
+        assert l2 <= 0.1, f"{k}: L2 rel grad err {l2} against the plain oracle"
     for k in ("encoder.conv1.weight", "encoder.layer3.0.downsample.0.weight", "decoder.blocks.3.conv1.0.weight"):
         gref = z["grad::" + k]
-        gg = dict(model.named_parameters())[k].grad.cpu().numpy()
-        assert np.abs(gg - gref).max() <= 2e-2 * np.abs(gref).max()
+        assert np.linalg.norm(grads_g[k].numpy() - gref) <= 0.1 * np.linalg.norm(gref)
     sd_o, sd_g = ref.state_dict(), model.state_dict()
     for k in sd_o:
         if "running_" in k:
             assert (sd_g[k].cpu() - sd_o[k]).abs().max().item() <= 1e-4 * (1 + sd_o[k].abs().max().item()), k
         if "num_batches_tracked" in k:
             assert int(sd_g[k]) == int(sd_o[k]) == 1
+    # the oracle with the engine's ReLU decisions
+    O.set_seed(42); ref2 = O.build_model()
+    ref2.train()
+    for name, mod in ref2.named_modules():
+        if isinstance(mod, torch.nn.ReLU):
+            queue = list(eng_masks[name])
+            mod.forward = lambda t, queue=queue: t * queue.pop(0).to(t.dtype)
+    lo2 = ref2(x)
+    O.total_loss(lo2, y).backward()
+    assert (lg.detach().cpu() - lo2.detach()).abs().max().item() <= 1e-3
+    named2 = dict(ref2.named_parameters())
+    for k, gg in grads_g.items():
+        go = named2[k].grad
+        rel = (gg - go).abs().max().item() / (go.abs().max().item() + 1e-12)
+        assert rel <= 1e-2, f"{k}: rel grad err {rel} against the oracle with the engine's ReLU masks"
 
 
 def test_three_step_trajectory_fp32(pair):

@@ -287,7 +287,7 @@ def test_conv_dgrad_split(dtn):
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(1, 32, 128, 64, 64), (2, 48, 32, 0, 16), (1, 24, 64, 64, 32)], ids=["d2", "d4_c16", "d3"])
+@pytest.mark.parametrize("shape", [(1, 32, 128, 64, 64), (2, 48, 32, 0, 16), (1, 24, 64, 64, 32), (2, 16, 128, 64, 64)], ids=["d2", "d4_c16", "d3", "d2_small"])
 def test_conv_dgrad_pool2(shape, dtn):
     """decoder conv1 data gradient with the nearest-x2 upsample backward fused: the up part comes out 2x2-summed at
     half resolution, the skip part at full resolution."""
@@ -316,19 +316,22 @@ def test_conv_dgrad_pool2(shape, dtn):
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
 @pytest.mark.parametrize("pool2", [0, 1])
-def test_conv_dgrad_fused_bn_relu_reduce(dtn, pool2):
-    """dgrad whose epilogue already applies the ReLU mask of the layer below and accumulates the BN-backward sums."""
+@pytest.mark.parametrize("shape", [(2, 24, 64, 0, 32), (2, 16, 128, 64, 64), (1, 32, 256, 128, 128)], ids=["c64", "dec2", "dec1"])
+def test_conv_dgrad_fused_bn_relu_reduce(dtn, pool2, shape):
+    """dgrad whose epilogue already applies the ReLU mask of the layer below and accumulates the BN-backward sums
+    (first output part only; the skip part of a concat gradient goes to y1 untouched)."""
     dt = DT[dtn]
-    N, H, Cc, K = 2, 24, 64, 32
+    N, H, Cc, Cskip, K = shape
     Hz = H // 2 if pool2 else H
-    w = gen(K, Cc, 3, 3, seed=241, scale=0.05)
+    w = gen(K, Cc + Cskip, 3, 3, seed=241, scale=0.05)
     dz = gen(N, K, H, H, seed=242)
     zb = rnd(gen(N, Cc, Hz, Hz, seed=243), dt)                 # raw output of the layer below
     g = torch.Generator().manual_seed(244)
     sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
-    xin = torch.zeros(N, Cc, H, H, dtype=torch.float64, requires_grad=True)
+    xin = torch.zeros(N, Cc + Cskip, H, H, dtype=torch.float64, requires_grad=True)
     F.conv2d(xin, rnd(w, dt).double(), padding=1).backward(rnd(dz, dt).double())
-    dy = xin.grad.float()
+    dfull = xin.grad.float()
+    dy = dfull[:, :Cc]
     if pool2:
         dy = F.avg_pool2d(dy, 2) * 4.0
     dy = rnd(dy, dt)
@@ -337,17 +340,21 @@ def test_conv_dgrad_fused_bn_relu_reduce(dtn, pool2):
     dzd, zbd = to_nhwc(dz, dt), to_nhwc(zb, dt)
     wt = D(w.permute(1, 2, 3, 0).contiguous().to(dt))
     y = torch.full((N, Hz, Hz, Cc), float("nan"), dtype=dt, device=dev())
+    y1 = torch.full((N, H, H, Cskip), float("nan"), dtype=dt, device=dev()) if Cskip else None
     sums = torch.zeros(REPL * 2 * Cc, dtype=torch.float64, device=dev())
     scd, shd = D(sc), D(sh)
     bnr = L_.vk_bnr(zbd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sums.data_ptr())
-    d = conv_desc(dt, N, H, H, H, H, Cc, 3, 1, 1, 1, mk_src(dzd, K))
+    d = conv_desc(dt, N, H, H, H, H, Cc + Cskip, 3, 1, 1, 1, mk_src(dzd, K))
     wp, _ = conv_w(d, wt)
-    vk._lib.check(vk.lib().vk_conv_dgrad_fused(C.byref(d), wp.data_ptr(), y.data_ptr(), None, 0, pool2, C.byref(bnr), st()))
+    vk._lib.check(vk.lib().vk_conv_dgrad_fused(C.byref(d), wp.data_ptr(), y.data_ptr(), y1.data_ptr() if Cskip else None,
+                                               Cc if Cskip else 0, pool2, C.byref(bnr), st()))
     torch.cuda.synchronize()
     got = from_nhwc(y)
     # elements whose pre-activation is within rounding of 0 may flip; compare where the mask is decided robustly
     pre = (zb * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).abs() > 1e-4
     assert ((got - gref).abs() * pre).max().item() <= tol(dt, dy) * 1.5
+    if Cskip:
+        assert (from_nhwc(y1) - dfull[:, Cc:]).abs().max().item() <= tol(dt, dfull)
     ss = sums.cpu().view(REPL, 2 * Cc).sum(0)
     gg = got.double()
     assert torch.allclose(ss[:Cc], gg.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3 * gg.abs().max().item() * 30)

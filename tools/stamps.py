@@ -31,6 +31,9 @@ torch.cuda.synchronize()
 b = buf.view(-1, 8).cpu().double()
 b = b[b[:, 7] > 0]
 m = b.mean(0)
-print(f"{name}: waves={len(b)} stages={int(m[7])}  per-wave cycles: load-issue {m[0]:.0f}  compute {m[1]:.0f}  store+wait {m[2]:.0f}  barrier {m[3]:.0f}  epilogue {m[4]:.0f}  loop-total {m[5]:.0f}  kernel-body {m[6]:.0f}")
+nst = int(m[7])
+mf = 48 * 16          # MFMA cycles per wave per stage at TP = TC = 4
+print(f"{name}: waves={len(b)} stages={nst}  per-wave cycles: prologue {m[5]:.0f}  [dma+halo-issue {m[0]:.0f}  compute {m[1]:.0f}  halo-store {m[2]:.0f}  barrier {m[3]:.0f}]  epilogue {m[4]:.0f}  kernel-body {m[6]:.0f}")
 tot = m[0] + m[1] + m[2] + m[3]
-print(f"   shares of the stage loop: load {m[0]/tot:.1%} compute {m[1]/tot:.1%} store {m[2]/tot:.1%} barrier {m[3]/tot:.1%};  ideal MFMA cycles per wave = {int(m[7]) * 48 * 16}")
+print(f"   stage loop {tot:.0f} cycles = {tot / nst:.0f} per stage: issue {m[0]/tot:.1%} compute {m[1]/tot:.1%} store {m[2]/tot:.1%} barrier {m[3]/tot:.1%};  own MFMA cycles per stage = {mf}")
+print(f"   kernel body: prologue {m[5]/m[6]:.1%}  loop {tot/m[6]:.1%}  epilogue {m[4]/m[6]:.1%}")

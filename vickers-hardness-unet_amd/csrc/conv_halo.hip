@@ -636,11 +636,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
     __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
   };
 
+#ifdef VK_STAMP
+  unsigned long long t_begin, t_pro, tk_load = 0, tk_comp = 0, tk_store = 0, tk_bar = 0;
+  VK_T(t_begin)
+#endif
   // ---- prologue: chunk 0 halo + stage 0 weights
   load_halo(0);
   dma_b(0, 0, 0);
   store_halo(Abuf);
   __syncthreads();                                        // also drains the LDS-DMA (vmcnt(0))
+  VK_T(t_pro)
 
   int st = 0;
   for (int cc = 0; cc < p.nchunks; ++cc) {
@@ -649,11 +654,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
     char* const Anext = Abuf + (ADB ? ((cc + 1) & 1) * Cfg::A_BYTES : 0);
 #pragma unroll
     for (int s = 0; s < 3; ++s, ++st) {
+#ifdef VK_STAMP
+      unsigned long long t0, t1, t2, t3, t4;
+#endif
+      VK_T(t0)
       // next stage's weights into the other buffer (all waves passed the barrier that closed its last readers)
       if (s < 2) dma_b(cc, s + 1, (st + 1) & 1);
       else if (next_chunk) dma_b(cc + 1, 0, (st + 1) & 1);
       if (s == 0 && next_chunk) load_halo(cc + 1);
+      VK_T(t1)
       compute(A + s * APS, Bbuf + (st & 1) * Cfg::B_BYTES + b_lane);
+      VK_T(t2)
       if (ADB) {
         if (s == 1 && next_chunk) store_halo(Anext);
       } else {
@@ -662,10 +673,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
           store_halo(Anext);
         }
       }
+      VK_T(t3)
       __syncthreads();
+      VK_T(t4)
+#ifdef VK_STAMP
+      tk_load += t1 - t0; tk_comp += t2 - t1; tk_store += t3 - t2; tk_bar += t4 - t3;
+#endif
     }
   }
+#ifdef VK_STAMP
+  unsigned long long te0, te1;
+  VK_T(te0)
+#endif
   halo_epilogue<T, TH, BN, TP, TC, NT>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
+#ifdef VK_STAMP
+  VK_T(te1)
+  if (p.stamps && lane == 0) {
+    unsigned long long* o = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+    o[0] = tk_load; o[1] = tk_comp; o[2] = tk_store; o[3] = tk_bar; o[4] = te1 - te0; o[5] = t_pro - t_begin; o[6] = te1 - t_begin; o[7] = st;
+  }
+#endif
 }
 
 // ---- C == 16 (16-bit types): decoder block 4 conv2 and the data gradients whose reduction runs over 16 channels.
@@ -906,7 +933,7 @@ static int col_select(const HaloParams& p, hipStream_t st) {
 
 template <typename T>
 static int halo_select(const HaloParams& p, hipStream_t st) {
-  static const bool old_loop = getenv("VK_HALO_ROWSTAGED") != nullptr;      // diagnostic: the v1 row-staged main loop
+  const bool old_loop = getenv("VK_HALO_ROWSTAGED") != nullptr;             // diagnostic: the v1 row-staged main loop
   if (!old_loop) return col_select<T>(p, st);
   const long tiles8 = (long)p.N * ((p.H + 7) / 8) * ((p.W + 15) / 16);
   const long tiles16 = (long)p.N * ((p.H + 15) / 16) * ((p.W + 15) / 16);
