@@ -161,7 +161,7 @@ def main():
                 tj = json.load(open(ROOT / "profiles" / "r01" / "traffic.json"))
                 if tag in tj:
                     roof["traffic"] = round(tj[tag]["fetch_bytes"] + tj[tag]["write_bytes"])
-                    roof["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch, FETCH doubled for gfx950)"
+                    roof["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py, mean per launch of the kernel symbol, FETCH doubled for gfx950)"
                     roof["algorithmic_bytes_per_launch"] = round(r["bytes"] / r["n"])
             except Exception:
                 pass

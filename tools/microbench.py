@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--prof", action="store_true")
+    ap.add_argument("--no-affine", action="store_true", help="sources without the BN+ReLU prologue (materialised activations)")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
     dev = torch.device("cuda:0")
@@ -46,7 +47,10 @@ def main():
             sc = torch.rand(c, device=dev) + 0.5
             sh = torch.randn(c, device=dev) * 0.1
             ts.append((t, sc, sh))
-            ss.append(L_.vk_src(t.data_ptr(), c, up, sc.data_ptr(), sh.data_ptr(), 1))
+            if a.no_affine:
+                ss.append(L_.vk_src(t.data_ptr(), c, up, None, None, 0))
+            else:
+                ss.append(L_.vk_src(t.data_ptr(), c, up, sc.data_ptr(), sh.data_ptr(), 1))
         s1 = ss[1] if len(ss) > 1 else L_.vk_src(None, 0, 0, None, None, 0)
         w = (torch.randn(K, 3, 3, Ctot, device=dev) * 0.05).to(dt)
         wt = (torch.randn(Ctot, 3, 3, K, device=dev) * 0.05).to(dt)
