@@ -302,6 +302,12 @@ struct vk_unet {
   int64_t* nbt = nullptr;
   char* ws = nullptr;
   bool bound = false;
+  // Weight gradients only feed the optimizer, so they run on a second (library-owned) stream beside the chain
+  // dgrad -> BN backward -> dgrad ... of the caller's stream: fork event after the layer's dz is final, join at the end of every
+  // backward stage (before the caller may all-reduce / read that stage's gradient bucket).  VK_NO_SIDE_STREAM=1 disables it.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_dirty = false;
   std::vector<PackEntry> pack_tab;
   std::vector<BnEvalEntry> bn_tab;
   std::map<std::string, std::pair<void*, std::vector<int>>> debug;
@@ -633,7 +639,16 @@ extern "C" int vk_unet_create(const vk_unet_config* cfg, vk_unet** out) {
   return VK_OK;
 }
 
-extern "C" void vk_unet_destroy(vk_unet* h) { delete h; }
+extern "C" void vk_unet_destroy(vk_unet* h) {
+  if (!h) return;
+  if (h->side) {
+    (void)hipStreamSynchronize(h->side);
+    (void)hipEventDestroy(h->ev_fork);
+    (void)hipEventDestroy(h->ev_join);
+    (void)hipStreamDestroy(h->side);
+  }
+  delete h;
+}
 extern "C" int vk_unet_num_tensors(const vk_unet* h) { return h ? (int)h->infos.size() : 0; }
 extern "C" int vk_unet_tensor_info(const vk_unet* h, int index, vk_tensor_info* out) {
   VK_CHECK_ARG(h && out && index >= 0 && index < (int)h->infos.size(), "vk_unet_tensor_info: bad index %d", index);
@@ -722,6 +737,11 @@ extern "C" int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_b
   if (!h->halo_tab.empty())
     VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_halo, h->halo_tab.data(), h->halo_tab.size() * sizeof(HaloPackEntry), hipMemcpyHostToDevice));
   VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_bn, h->bn_tab.data(), h->bn_tab.size() * sizeof(BnEvalEntry), hipMemcpyHostToDevice));
+  if (h->cfg.training && !h->side && !getenv("VK_NO_SIDE_STREAM")) {
+    VK_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    VK_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    VK_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  }
   h->bound = true;
   return VK_OK;
 }
@@ -857,9 +877,25 @@ int bn_relu_bwd_inplace(vk_unet* h, ConvL& c, bool prereduced, hipStream_t st) {
   return vk_bn_bwd_apply(h->cfg.dtype, pixels, c.K, c.g, c.z, prereduced ? 0 : 1, b.scale, b.shift, nullptr, b.coef, c.g, nullptr, 0, st);
 }
 
+// stream the weight-gradient kernels run on: the side stream, forked here behind everything enqueued on `st` so far
+hipStream_t wgrad_stream(vk_unet* h, hipStream_t st) {
+  if (!h->side) return st;
+  if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return st;
+  h->side_dirty = true;
+  return h->side;
+}
+
+int join_side(vk_unet* h, hipStream_t st) {
+  if (!h->side || !h->side_dirty) return VK_OK;
+  VK_CHECK_HIP(hipEventRecord(h->ev_join, h->side));
+  VK_CHECK_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+  h->side_dirty = false;
+  return VK_OK;
+}
+
 int conv_wgrad(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, hipStream_t st) {
   vk_conv_desc d = conv_desc(h, c, s0, s1);
-  return vk_conv_wgrad(&d, c.g, h->grads + c.w_off, h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, st);
+  return vk_conv_wgrad(&d, c.g, h->grads + c.w_off, h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, wgrad_stream(h, st));
 }
 
 vk_bnr bnr_of(vk_unet* h, ConvL& target) {     // fused BN+ReLU backward reduce descriptor for the layer `target`
@@ -1018,7 +1054,7 @@ int backward_stem(vk_unet* h, hipStream_t st) {
   // stem.g holds the skip gradient of f1 (from decoder block 3); add the maxpool path
   RET_IF(vk_maxpool_bwd(h->cfg.dtype, N, S / 2, S / 2, 64, h->ws + h->off_gpool, (const uint8_t*)(h->ws + h->off_argmax), stem.g, st));
   RET_IF(bn_relu_bwd_inplace(h, stem, false, st));
-  return vk_stem_wgrad(h->cfg.dtype, N, S, S, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, st);
+  return vk_stem_wgrad(h->cfg.dtype, N, S, S, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, wgrad_stream(h, st));
 }
 
 int backward_stage(vk_unet* h, const float* dlogits, int stage, hipStream_t st) {
@@ -1069,6 +1105,11 @@ int backward_stage(vk_unet* h, const float* dlogits, int stage, hipStream_t st) 
 extern "C" int vk_unet_backward(vk_unet* h, const float* dlogits, int stage_begin, int stage_end, void* stream) {
   VK_CHECK_ARG(h && h->bound && h->cfg.training && h->grads, "vk_unet_backward: needs a bound training plan");
   VK_CHECK_ARG(stage_begin >= 0 && stage_end <= (int)h->buckets.size() && stage_begin <= stage_end, "vk_unet_backward: bad stage range");
-  for (int s = stage_begin; s < stage_end; ++s) RET_IF(backward_stage(h, dlogits, s, (hipStream_t)stream));
+  for (int s = stage_begin; s < stage_end; ++s) {
+    const int rc = backward_stage(h, dlogits, s, (hipStream_t)stream);
+    const int rj = join_side(h, (hipStream_t)stream);        // also after a failed stage: never leave the side stream un-joined
+    if (rc != VK_OK) return rc;
+    if (rj != VK_OK) return rj;
+  }
   return VK_OK;
 }
