@@ -82,6 +82,7 @@ SIGNATURES = {
     "vk_amp_check_inf": (ci, [sz, vp, vp, vp]),
     "vk_unet_create": (ci, [P(vk_unet_config), P(vp)]),
     "vk_unet_destroy": (None, [vp]),
+    "vk_unet_set_side_stream": (ci, [vp, ci]),
     "vk_unet_num_tensors": (ci, [vp]),
     "vk_unet_tensor_info": (ci, [vp, ci, P(vk_tensor_info)]),
     "vk_unet_param_numel": (i64, [vp]),

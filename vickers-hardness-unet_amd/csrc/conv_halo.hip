@@ -48,6 +48,8 @@ struct HaloParams {
   // fused BatchNorm+ReLU backward reduce on the first output part: g = y * [z*scale+shift > 0] is stored instead of y and
   // sum(g), sum(g*z) go to bnr_sums [VK_STATS_REPLICAS][2][ld0]
   unsigned long long* stamps;   // diagnostic builds (-DVK_STAMP) only
+  int dbg;                      // timing experiments (VK_COL_DBG, results are WRONG by construction): 1 = weight descriptor with zero
+                                // records, 2 = no LDS-DMA in the loop, 4 = no halo refresh in the loop, 8 = no stage barriers
   const void* bnr_z;
   const float* bnr_scale;
   const float* bnr_shift;
@@ -659,22 +661,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
 #endif
       VK_T(t0)
       // next stage's weights into the other buffer (all waves passed the barrier that closed its last readers)
-      if (s < 2) dma_b(cc, s + 1, (st + 1) & 1);
-      else if (next_chunk) dma_b(cc + 1, 0, (st + 1) & 1);
-      if (s == 0 && next_chunk) load_halo(cc + 1);
+      if (!(p.dbg & 2)) {
+        if (s < 2) dma_b(cc, s + 1, (st + 1) & 1);
+        else if (next_chunk) dma_b(cc + 1, 0, (st + 1) & 1);
+      }
+      if (s == 0 && next_chunk && !(p.dbg & 4)) load_halo(cc + 1);
       VK_T(t1)
       compute(A + s * APS, Bbuf + (st & 1) * Cfg::B_BYTES + b_lane);
       VK_T(t2)
       if (ADB) {
-        if (s == 1 && next_chunk) store_halo(Anext);
+        if (s == 1 && next_chunk && !(p.dbg & 4)) store_halo(Anext);
       } else {
-        if (s == 2 && next_chunk) {
+        if (s == 2 && next_chunk && !(p.dbg & 4)) {
           __syncthreads();                                // every wave is done reading this chunk's halo
           store_halo(Anext);
         }
       }
       VK_T(t3)
-      __syncthreads();
+      if (!(p.dbg & 8)) __syncthreads();
       VK_T(t4)
 #ifdef VK_STAMP
       tk_load += t1 - t0; tk_comp += t2 - t1; tk_store += t3 - t2; tk_bar += t4 - t3;
@@ -1003,6 +1007,8 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, 
   p.accumulate = accumulate;
   p.pool2 = pool2;
   p.stamps = nullptr;
+  p.dbg = getenv("VK_COL_DBG") ? atoi(getenv("VK_COL_DBG")) : 0;
+  if (p.dbg & 1) p.w_bytes = 0;
 #ifdef VK_STAMP
   { extern unsigned long long* g_vk_stamp_buf; p.stamps = g_vk_stamp_buf; }
 #endif

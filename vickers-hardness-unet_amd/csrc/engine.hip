@@ -737,11 +737,7 @@ extern "C" int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_b
   if (!h->halo_tab.empty())
     VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_halo, h->halo_tab.data(), h->halo_tab.size() * sizeof(HaloPackEntry), hipMemcpyHostToDevice));
   VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_bn, h->bn_tab.data(), h->bn_tab.size() * sizeof(BnEvalEntry), hipMemcpyHostToDevice));
-  if (h->cfg.training && !h->side && !getenv("VK_NO_SIDE_STREAM")) {
-    VK_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    VK_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    VK_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  }
+  if (h->cfg.training && !h->side && !getenv("VK_NO_SIDE_STREAM")) RET_IF(vk_unet_set_side_stream(h, 1));
   h->bound = true;
   return VK_OK;
 }
@@ -771,6 +767,24 @@ extern "C" int vk_unet_refresh_weights(vk_unet* h, void* stream) {
     case VK_F16: return refresh_t<f16_t>(h, st);
   }
   return VK_ERR_ARG;
+}
+
+extern "C" int vk_unet_set_side_stream(vk_unet* h, int enable) {
+  VK_CHECK_ARG(h, "vk_unet_set_side_stream: null plan");
+  if (enable && !h->side && h->cfg.training) {
+    VK_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    VK_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    VK_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  } else if (!enable && h->side) {
+    VK_CHECK_HIP(hipStreamSynchronize(h->side));
+    (void)hipEventDestroy(h->ev_fork);
+    (void)hipEventDestroy(h->ev_join);
+    (void)hipStreamDestroy(h->side);
+    h->side = nullptr;
+    h->ev_fork = h->ev_join = nullptr;
+    h->side_dirty = false;
+  }
+  return VK_OK;
 }
 
 extern "C" int vk_unet_zero_grad(vk_unet* h, void* stream) {

@@ -265,23 +265,26 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
   }
   __syncthreads();
   int it = 0;
+  const int dbg = p.dbg_skip_epilogue >> 1;     // timing experiments (VK_WH_DBG, results WRONG): 1 no tile loads, 2 no LDS tile stores, 4 no MFMA steps, 8 no barriers
   for (; t < p.ntiles; t += p.splits, ++it) {
     const bool more = t + p.splits < p.ntiles;
-    if (more) load_tile(t + p.splits);
+    if (more && !(dbg & 1)) load_tile(t + p.splits);
     const char* Zs = smem + (it & 1) * STAGE;
     const char* Vs = Zs + PX * ZSB;
-    if (WS) {
-      compute_step(Zs, Vs, wave);
-    } else {
+    if (!(dbg & 4)) {
+      if (WS) {
+        compute_step(Zs, Vs, wave);
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) compute_step(Zs, Vs, ks);
+        for (int ks = 0; ks < 4; ++ks) compute_step(Zs, Vs, ks);
+      }
     }
-    if (more) store_tile((it + 1) & 1);
-    __syncthreads();
+    if (more && !(dbg & 2)) store_tile((it + 1) & 1);
+    if (!(dbg & 8)) __syncthreads();
   }
 
   // ---- epilogue
-  if (p.dbg_skip_epilogue) {
+  if (p.dbg_skip_epilogue & 1) {
     if (acc[0][0][0][0] == 123.456f) p.dw[0] = 1.f;     // keep the accumulators alive
     return;
   }
@@ -378,7 +381,7 @@ static int launch_wh(WhParams p, size_t slab_bytes, hipStream_t st) {
   if (splits < 1) splits = 1;
   if ((long)splits * kt * ct < wh_min_blocks()) return VK_ERR_UNSUPPORTED;  // too few workgroups to fill the chip
   p.splits = splits;
-  p.dbg_skip_epilogue = getenv("VK_WH_DBG_NOEPI") ? 1 : 0;
+  p.dbg_skip_epilogue = (getenv("VK_WH_DBG_NOEPI") ? 1 : 0) | ((getenv("VK_WH_DBG") ? atoi(getenv("VK_WH_DBG")) : 0) << 1);
   const size_t slab_need = (size_t)splits * p.K * 9 * p.C * sizeof(float);
   if (!p.slab || slab_need > slab_bytes || getenv("VK_WH_NO_SLAB")) p.slab = nullptr;
   dim3 grid(kt, ct, splits);

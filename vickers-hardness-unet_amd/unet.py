@@ -331,6 +331,9 @@ class Unet(nn.Module):
             check(L.vk_unet_zero_grad(plan.h, st), "vk_unet_zero_grad")
             self._attach_grads()
         red = self._reducer
+        if red is not None and getattr(red, "enabled", True) and not getattr(plan, "_side_off", False):
+            check(L.vk_unet_set_side_stream(plan.h, 0), "vk_unet_set_side_stream")    # see include/vk_unet.h
+            plan._side_off = True
         for s in range(plan.nbuckets):
             check(L.vk_unet_backward(plan.h, _lib.ptr(dlogits), s, s + 1, st), "vk_unet_backward")
             if red is not None:
