@@ -172,6 +172,7 @@ def main():
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, single-GPU runs only)
     cpu = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = _usable_cores()
         torch.set_num_threads(cores)
@@ -202,6 +203,28 @@ def main():
         _log(f"cpu baseline done: {cdt / nst:.2f} s/step")
         cpu = {"value": round(bs * nst / cdt, 3), "unit": "images/s", "cores": cores, "kind": "port", "sample": sample,
                "cpu_model": _cpu_model()}
+        # ---- "mask IoU vs ref" (BASELINE.json metric, second half): the weights the timed steps left behind, loaded into the
+        # oracle (same 278 state-dict keys), fp32 eval forward of both on the same images (reference validate(), train.py:495-529)
+        try:
+            ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+            ref.eval(); model.eval()
+            saved = model.compute_dtype
+            model.compute_dtype = torch.float32
+            with torch.no_grad():
+                lo = ref(xc)
+                lg = model(xc.to(dev)).float().cpu()
+            model.compute_dtype = saved
+            po, pg = torch.sigmoid(lo), torch.sigmoid(lg)
+            mo, mg = po > 0.5, pg > 0.5
+            inter, union = (mo & mg).sum().item(), (mo | mg).sum().item()
+            parity = {"mask_iou_vs_target_engine": round(float(O.iou_coef(pg, yc)), 6), "mask_iou_vs_target_oracle": round(float(O.iou_coef(po, yc)), 6),
+                      "mask_agreement_iou": round(inter / union, 6) if union else 1.0,
+                      "max_abs_logit_err": round((lg - lo).abs().max().item(), 6),
+                      "sample": f"fp32 eval forward, bs={bs}, {S}x{S}, weights after the timed steps"}
+            parity["abs_iou_diff"] = round(abs(parity["mask_iou_vs_target_engine"] - parity["mask_iou_vs_target_oracle"]), 6)
+            _log(f"parity leg: {parity}")
+        except Exception as e:      # the baseline leg must never take the bench line down
+            parity = {"error": repr(e)}
 
     if rank == 0:
         ips = world * N * args.steps / dt
@@ -217,7 +240,7 @@ def main():
                        "parallelism": f"dp{world} (RCCL all-reduce of fp32 gradients, 10 buckets overlapped with backward)" if world > 1 else "single GPU"},
             "conv_tflops": round((TRAIN_GFLOP_PER_IMG_512 if args.mode == "train" else FWD_GFLOP_PER_IMG_512) * (S / 512) ** 2 * ips / 1e3, 2),
             "last_loss": last,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(rec), flush=True)
     if world > 1 or force_dist:
