@@ -202,13 +202,23 @@ __global__ __launch_bounds__(256) void k_bn_add_relu(size_t pixels, int C, const
   const size_t stride = (size_t)gridDim.x * blockDim.x;  // multiple of CV => the channel group of a thread is fixed
   const size_t t0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   const int c0 = (int)(t0 % CV) * VE;
+  // per-workgroup coefficient table in LDS, one thread per channel: 32 scalar global loads per thread in this prologue cost
+  // more than the whole tensor pass on the small (layer3/4) blocks (35 us floor per launch, measured)
+  __shared__ float cf[4][512];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    cf[0][c] = scale[c];
+    cf[1][c] = shift[c];
+    cf[2][c] = rscale ? rscale[c] : 1.f;
+    cf[3][c] = rscale ? rshift[c] : 0.f;
+  }
+  __syncthreads();
   float sc[VE], sh[VE], rsc[VE], rsh[VE];
 #pragma unroll
   for (int j = 0; j < VE; ++j) {
-    sc[j] = scale[c0 + j];
-    sh[j] = shift[c0 + j];
-    rsc[j] = rscale ? rscale[c0 + j] : 1.f;
-    rsh[j] = rscale ? rshift[c0 + j] : 0.f;
+    sc[j] = cf[0][c0 + j];
+    sh[j] = cf[1][c0 + j];
+    rsc[j] = cf[2][c0 + j];
+    rsh[j] = cf[3][c0 + j];
   }
   for (size_t i = t0; i < total; i += U * stride) {
     u32x4_t zv[U], rv[U];
@@ -840,7 +850,9 @@ extern "C" int vk_bn_add_relu(vk_dtype dtype, size_t pixels, int C, const void* 
   VK_CHECK_ARG(z && scale && shift && res && out && C % 8 == 0, "vk_bn_add_relu: bad argument");
   hipStream_t st = (hipStream_t)stream;
   vkh::ProfScope ps_("bn_add_relu", st, 0.0, (double)pixels * C * (dtype == VK_F32 ? 4.0 : 2.0) * 3.0);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_add_relu<T>, dim3(grid_for(pixels * (C / ElemTraits<T>::kVec))), dim3(256), 0, st, pixels, C,
+  VK_CHECK_ARG(C <= 512, "vk_bn_add_relu: C=%d unsupported", C);
+  // four vectors per thread (one unrolled pass) before the grid grows; the grid stays a multiple of C/VE threads
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_add_relu<T>, dim3(grid_for((pixels * (C / ElemTraits<T>::kVec) + 3) / 4)), dim3(256), 0, st, pixels, C,
                                        (const T*)z, scale, shift, (const T*)res, rscale, rshift, (T*)out));
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
