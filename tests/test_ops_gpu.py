@@ -441,10 +441,11 @@ def test_conv_wgrad_upsample_concat(dtn, wgrad_path):
     assert err <= (1e-4 if dt == torch.float32 else 2e-3) * ref.abs().max().item(), err
 
 
-@pytest.mark.parametrize("dtn", ["f32", "bf16"])
-def test_stem_wgrad(dtn):
+@pytest.mark.parametrize("dtn", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("S", [64, 96, 160])
+def test_stem_wgrad(dtn, S):
     dt = DT[dtn]
-    N, S = 2, 64
+    N = 2
     x = gen(N, 3, S, S, seed=61)
     dz = gen(N, 64, S // 2, S // 2, seed=62)
     wv = torch.zeros(64, 3, 7, 7, dtype=torch.float64, requires_grad=True)

@@ -385,9 +385,155 @@ int conv_wgrad_impl(const vk_conv_desc* d, const void* dz, float* dw, void* work
   return dispatch_w(d->dtype, p, cmin, st);
 }
 
+// ---- stem (7x7 stride 2, 3->64) weight gradient for the 16-bit types: one workgroup stages a 4 x 32 output-pixel tile of dz
+// and the 13 x 72 input pixels under it ONCE and accumulates all seven filter rows from them (the tap-by-tap kernel above
+// streams dz once per filter row: 7 passes over the 268 MB tensor).
+//   dW[k][r][s][c] = sum_px dz[px][k] * x4[2y + r - 3][2x + s - 3][c]
+// GEMM view per filter row r: A = dz^T (k x pixels), B[px][v] with v = (s, c) = the 64 contiguous bytes starting at input pixel
+// (2y + r - 3, 2x - 3): overlapping windows of the staged rows, read by ds_read_b64_tr_b16 with per-lane addresses.
+// Wave w owns output channels 16w..16w+15 and all 7 x 2 (s-half) tiles: 56 accumulator registers.  Persistent workgroups,
+// double-buffered LDS, next tile's loads in flight (registers) under the MFMAs.  fp32 atomics at the end (as above).
+struct StemWgParams {
+  const void* x4;
+  const void* dz;
+  float* dw;
+  uint32_t x_bytes, dz_bytes;
+  int N, H, W, Ho, Wo, tiles_x, tiles_y, ntiles;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_stem_wgrad(const StemWgParams p) {
+  static_assert(sizeof(T) == 2, "16-bit types only");
+  constexpr int ZSB = 160;                   // dz pixel row: 64 k x 2 B + 32 pad (conflict-free transposed reads)
+  constexpr int XW = 72, XROWS = 13;         // staged input: 13 rows x 72 pixels x 8 B
+  constexpr int Z_BYTES = 128 * ZSB, X_BYTES = XROWS * XW * 8;
+  constexpr int STAGE = (Z_BYTES + X_BYTES + 255) / 256 * 256;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const __amdgpu_buffer_rsrc_t rsx = make_rsrc(p.x4, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rsz = make_rsrc(p.dz, p.dz_bytes);
+
+  u32x4_t zr[4], zr_n[4];
+  u32x2_t xr[4], xr_n[4];
+  auto fetch = [&](int t, u32x4_t (&zv)[4], u32x2_t (&xv)[4]) {
+    int bt = t;
+    const int tx = bt % p.tiles_x;
+    bt /= p.tiles_x;
+    const int ty = bt % p.tiles_y;
+    const int n = bt / p.tiles_y;
+    const int y0 = ty * 4, x0 = tx * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx >> 3, vec = idx & 7;
+      const int y = y0 + (px >> 5), x = x0 + (px & 31);
+      const bool ok = y < p.Ho && x < p.Wo;
+      zv[i] = buf_load16(rsz, ok ? (uint32_t)(((n * p.Ho + y) * p.Wo + x) * 64 + vec * 8) * 2u : kOOB);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int ry = idx / XW, rx = idx - ry * XW;
+      const int iy = 2 * y0 - 3 + ry, ix = 2 * x0 - 3 + rx;
+      const bool ok = idx < XROWS * XW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      xv[i] = __builtin_amdgcn_raw_buffer_load_b64(rsx, ok ? (uint32_t)(((n * p.H + iy) * p.W + ix) * 4) * 2u : kOOB, 0, 0);
+    }
+  };
+  auto stage = [&](int st, const u32x4_t (&zv)[4], const u32x2_t (&xv)[4]) {
+    char* Zs = smem + st * STAGE;
+    char* Xs = Zs + Z_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      *reinterpret_cast<u32x4_t*>(Zs + (idx >> 3) * ZSB + (idx & 7) * 16) = zv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < XROWS * XW) *reinterpret_cast<u32x2_t*>(Xs + idx * 8) = xv[i];
+    }
+  };
+
+  f32x4_t acc[7][2];
+#pragma unroll
+  for (int r = 0; r < 7; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[r][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // transposed-read lane geometry: lane j of 16-lane group g supplies pixel 4g + (j >> 2), elements 4 (j & 3) .. +3
+  const int pl = 4 * (lane >> 4) + ((lane & 15) >> 2), q = lane & 3;
+  const int lane_z = pl * ZSB + (wave * 16 + 4 * q) * 2;
+  const int lane_x = (2 * pl + q) * 8;
+
+  int t = blockIdx.x;
+  if (t < p.ntiles) {
+    fetch(t, zr, xr);
+    stage(0, zr, xr);
+  }
+  __syncthreads();
+  for (int it = 0; t < p.ntiles; t += gridDim.x, ++it) {
+    const bool has_next = t + (int)gridDim.x < p.ntiles;
+    if (has_next) fetch(t + gridDim.x, zr_n, xr_n);
+    const char* Zs = smem + (it & 1) * STAGE;
+    const char* Xs = Zs + Z_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {                       // one output row = 32 pixels of reduction
+      const char* zb = Zs + lane_z + (32 * ks) * ZSB;
+      const u32x2_t zl = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(zb)));
+      const u32x2_t zh = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(zb + 16 * ZSB)));
+      const u32x4_t zf = u32x4_t{zl[0], zl[1], zh[0], zh[1]};
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const char* xb = Xs + lane_x + ((2 * ks + r) * XW + 4 * h) * 8;
+          const u32x2_t xl = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xb)));
+          const u32x2_t xh = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xb + 32 * 8)));
+          acc[r][h] = Mma<T>::run(zf, u32x4_t{xl[0], xl[1], xh[0], xh[1]}, acc[r][h]);
+        }
+    }
+    if (has_next) {
+      stage((it + 1) & 1, zr_n, xr_n);                     // that buffer was last read one iteration ago, before the barrier below
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { zr[i] = zr_n[i]; xr[i] = xr_n[i]; }
+    }
+    __syncthreads();
+  }
+  // D[row = (lane >> 4) * 4 + e -> k][col = lane & 15 -> (s - 4h, c)]
+#pragma unroll
+  for (int r = 0; r < 7; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int sx = 4 * h + ((lane & 15) >> 2), ci = lane & 3;
+      if (sx < 7 && ci < 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = wave * 16 + (lane >> 4) * 4 + e;
+          atomicAdd(p.dw + (((size_t)k * 7 + r) * 7 + sx) * 3 + ci, acc[r][h][e]);
+        }
+      }
+    }
+}
+
 int stem_wgrad_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void* dz, float* dw, hipStream_t st) {
   VK_CHECK_ARG(x4 && dz && dw, "vk_stem_wgrad: null argument");
   const int eb = dt == VK_F32 ? 4 : 2;
+  if (dt != VK_F32 && !getenv("VK_STEM_WGRAD_TAPS") && (size_t)N * (H / 2) * (W / 2) * 64 * 2 < (1ull << 31)) {
+    StemWgParams q;
+    q.x4 = x4; q.dz = dz; q.dw = dw;
+    q.N = N; q.H = H; q.W = W; q.Ho = H / 2; q.Wo = W / 2;
+    q.x_bytes = (uint32_t)((size_t)N * H * W * 4 * 2);
+    q.dz_bytes = (uint32_t)((size_t)N * q.Ho * q.Wo * 64 * 2);
+    q.tiles_x = (q.Wo + 31) / 32; q.tiles_y = (q.Ho + 3) / 4;
+    q.ntiles = N * q.tiles_y * q.tiles_x;
+    const int nb = q.ntiles < 512 ? q.ntiles : 512;
+    static const std::string tag = "wgrad_stem_16b";
+    vkh::ProfScope ps(tag.c_str(), st, 2.0 * (double)N * q.Ho * q.Wo * 64.0 * 147.0, ((double)N * H * W * 4 + (double)N * q.Ho * q.Wo * 64) * 2.0 + 64.0 * 147 * 4);
+    if (dt == VK_BF16) hipLaunchKernelGGL(k_stem_wgrad<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, q);
+    else hipLaunchKernelGGL(k_stem_wgrad<f16_t>, dim3((unsigned)nb), dim3(256), 0, st, q);
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
+  }
   WgradParams p;
   p.s0 = SrcDevW{x4, nullptr, nullptr, 4, 0, 0, (uint32_t)((size_t)N * H * W * 4 * eb)};
   p.s1 = SrcDevW{nullptr, nullptr, nullptr, 0, 0, 0, 0u};

@@ -658,26 +658,57 @@ __global__ __launch_bounds__(256) void k_head_wgrad(int N, int H, int W, int til
 #pragma unroll
   for (int j = 0; j < 144; ++j) gw[j] = 0.f;
   float gb = 0.f;
-  int it = 0;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
+  // software pipeline over this workgroup's tiles: the next tile's activations (raw vectors) and dlogits halo are loaded
+  // into registers before the current tile's 144 FMAs per pixel, so the HBM latency is paid once, not once per tile
+  constexpr int VE = ElemTraits<T>::kVec, VPP = 16 / VE;
+  u32x4_t ar[VPP], ar_n[VPP];
+  float dr[2], dr_n[2];
+  bool ok = false, ok_n = false;
+  auto fetch = [&](int t, u32x4_t (&av)[VPP], float (&dv)[2], bool& inb) {
     int bt = t;
     const int tx0 = bt % tiles_x;
     bt /= tiles_x;
     const int ty0 = bt % tiles_y;
     const int n = bt / tiles_y;
     const int y0 = ty0 * 16, x0 = tx0 * 16;
-    float* d = dt[it & 1];
-    for (int hp = tid; hp < 324; hp += 256) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int hp = tid + k * 256;
       const int hy = hp / 18, hx = hp - hy * 18;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-      d[hp] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? dl[((size_t)n * H + y) * W + x] : 0.f;
+      dv[k] = (hp < 324 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? dl[((size_t)n * H + y) * W + x] : 0.f;
     }
     const int y = y0 + ty, x = x0 + tx;
+    inb = y < H && x < W;
+    const T* zp = z + (((size_t)n * H + (inb ? y : 0)) * W + (inb ? x : 0)) * 16;
+#pragma unroll
+    for (int v = 0; v < VPP; ++v) av[v] = *reinterpret_cast<const u32x4_t*>(zp + v * VE);
+  };
+  int t = blockIdx.x;
+  if (t < ntiles) {
+    fetch(t, ar, dr, ok);
+    dt[0][tid] = dr[0];
+    if (tid + 256 < 324) dt[0][tid + 256] = dr[1];
+  }
+  __syncthreads();
+  for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+    const bool has_next = t + (int)gridDim.x < ntiles;
+    if (has_next) fetch(t + gridDim.x, ar_n, dr_n, ok_n);
+    const float* d = dt[it & 1];
     float a[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = 0.f;
-    if (y < H && x < W) load_act16<T>(z + (((size_t)n * H + y) * W + x) * 16, sc, sh, affine, relu != 0, a);
-    __syncthreads();                 // dl tile ready (the other buffer is free: it was last read two iterations ago)
+    for (int v = 0; v < VPP; ++v) Vec16<T>::unpack(ar[v], a + v * VE);
+    if (affine) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        a[j] = fmaf(a[j], sc[j], sh[j]);
+        if (relu) a[j] = fmaxf(a[j], 0.f);
+      }
+    }
+    if (!ok) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[j] = 0.f;
+    }
     gb += d[(ty + 1) * 18 + tx + 1];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -687,6 +718,15 @@ __global__ __launch_bounds__(256) void k_head_wgrad(int N, int H, int W, int til
 #pragma unroll
         for (int j = 0; j < 16; ++j) gw[(r * 3 + s) * 16 + j] = fmaf(dv, a[j], gw[(r * 3 + s) * 16 + j]);
       }
+    if (has_next) {                  // the other dlogits buffer was last read one iteration ago, before the barrier below
+      float* dn = dt[(it + 1) & 1];
+      dn[tid] = dr_n[0];
+      if (tid + 256 < 324) dn[tid + 256] = dr_n[1];
+#pragma unroll
+      for (int v = 0; v < VPP; ++v) ar[v] = ar_n[v];
+      ok = ok_n;
+    }
+    __syncthreads();
   }
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
