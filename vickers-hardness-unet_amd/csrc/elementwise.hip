@@ -521,22 +521,42 @@ __global__ __launch_bounds__(256) void k_head_fwd(int N, int H, int W, int tiles
   const int n = bt / tiles_y;
   const int y0 = ty0 * 16, x0 = tx0 * 16;
   const bool affine = scale != nullptr;
-  for (int v = tid; v < 324 * VPP; v += 256) {
-    const int hp = v / VPP, vec = v % VPP;
+  // 256 % VPP == 0: a thread's vectors always cover the same channels -> scale/shift once, not 2 x 8 scalar loads per vector;
+  // all of the thread's halo vectors are requested before the first one is consumed
+  const int vec = tid % VPP;
+  float sc[VE], sh[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) { sc[j] = affine ? scale[vec * VE + j] : 1.f; sh[j] = affine ? shift[vec * VE + j] : 0.f; }
+  constexpr int NHV = (324 * VPP + 255) / 256;
+  u32x4_t raw[NHV];
+  bool inb[NHV];
+#pragma unroll
+  for (int i = 0; i < NHV; ++i) {
+    const int v = tid + i * 256;
+    const int hp = v / VPP;
     const int hy = hp / 18, hx = hp - hy * 18;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    inb[i] = v < 324 * VPP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    raw[i] = u32x4_t{0, 0, 0, 0};
+    if (inb[i]) raw[i] = *reinterpret_cast<const u32x4_t*>(z + (((size_t)n * H + y) * W + x) * 16 + vec * VE);
+  }
+#pragma unroll
+  for (int i = 0; i < NHV; ++i) {
+    const int v = tid + i * 256;
+    if (v >= 324 * VPP) continue;
+    const int hp = v / VPP;
     float f[VE];
+    Vec16<T>::unpack(raw[i], f);
+    if (affine) {
 #pragma unroll
-    for (int j = 0; j < VE; ++j) f[j] = 0.f;
-    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
-      Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(z + (((size_t)n * H + y) * W + x) * 16 + vec * VE), f);
-      if (affine) {
-#pragma unroll
-        for (int j = 0; j < VE; ++j) {
-          f[j] = fmaf(f[j], scale[vec * VE + j], shift[vec * VE + j]);
-          if (relu) f[j] = fmaxf(f[j], 0.f);
-        }
+      for (int j = 0; j < VE; ++j) {
+        f[j] = fmaf(f[j], sc[j], sh[j]);
+        if (relu) f[j] = fmaxf(f[j], 0.f);
       }
+    }
+    if (!inb[i]) {
+#pragma unroll
+      for (int j = 0; j < VE; ++j) f[j] = 0.f;
     }
 #pragma unroll
     for (int j = 0; j < VE; j += 4) *reinterpret_cast<f32x4_t*>(&tile[hp * PS + vec * VE + j]) = f32x4_t{f[j], f[j + 1], f[j + 2], f[j + 3]};
@@ -587,10 +607,20 @@ __global__ __launch_bounds__(256) void k_head_dgrad(int N, int H, int W, int til
     const int n = bt / tiles_y;
     const int y0 = ty0 * 16, x0 = tx0 * 16;
     float* d = dt[it & 1];
+    // the z vectors of the fused BN+ReLU backward are requested first: their latency runs under the dlogits staging and the FMAs
+    const int y = y0 + ty, x = x0 + tx;
+    const size_t off = (((size_t)n * H + (y < H ? y : 0)) * W + (x < W ? x : 0)) * 16;
+    u32x4_t zraw[16 / VE];
+#pragma unroll
+    for (int v = 0; v < 16 / VE; ++v) zraw[v] = u32x4_t{0, 0, 0, 0};
+    if (bnr_z && y < H && x < W) {
+#pragma unroll
+      for (int v = 0; v < 16 / VE; ++v) zraw[v] = *reinterpret_cast<const u32x4_t*>(bnr_z + off + v * VE);
+    }
     for (int hp = tid; hp < 324; hp += 256) {
       const int hy = hp / 18, hx = hp - hy * 18;
-      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-      d[hp] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? dl[((size_t)n * H + y) * W + x] : 0.f;
+      const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+      d[hp] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? dl[((size_t)n * H + yy) * W + xx] : 0.f;
     }
     __syncthreads();                 // (double-buffered tile: the other buffer was last read two iterations ago)
     float o[16];
@@ -604,16 +634,14 @@ __global__ __launch_bounds__(256) void k_head_dgrad(int N, int H, int W, int til
 #pragma unroll
         for (int j = 0; j < 16; ++j) o[j] = fmaf(dv, w[(r * 3 + s) * 16 + j], o[j]);
       }
-    const int y = y0 + ty, x = x0 + tx;
     if (y < H && x < W) {
-      const size_t off = (((size_t)n * H + y) * W + x) * 16;
 #pragma unroll
       for (int v = 0; v < 16 / VE; ++v) {
         u32x4_t pk = Vec16<T>::pack(o + v * VE);
         if (bnr_z) {       // g = dy * [relu(bn(z)) > 0]; sums over the stored values
           float g[VE], zf[VE];
           Vec16<T>::unpack(pk, g);
-          Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(bnr_z + off + v * VE), zf);
+          Vec16<T>::unpack(zraw[v], zf);
 #pragma unroll
           for (int j = 0; j < VE; ++j) {
             if (!(fmaf(zf[j], bsc[v * VE + j], bsh[v * VE + j]) > 0.f)) g[j] = 0.f;
@@ -749,16 +777,23 @@ __global__ __launch_bounds__(256) void k_head_wgrad(int N, int H, int W, int til
 // ------------------------------------------------------------------------------------------------
 // K10: BCE-with-logits (mean) + binary Dice (batch-global, smooth 0, eps 1e-7)
 __global__ __launch_bounds__(256) void k_loss_reduce(size_t count, const float* __restrict__ x, const float* __restrict__ y,
-                                                     double* sums) {
+                                                     double* sums, int vec_ok) {
   float bce = 0.f, py = 0.f, ps = 0.f, ys = 0.f;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
-    const float xv = x[i], yv = y[i];
+  auto term = [&](float xv, float yv) {
     bce += fmaxf(xv, 0.f) - xv * yv + log1pf(expf(-fabsf(xv)));
     const float p = 1.f / (1.f + expf(-xv));
     py += p * yv;
     ps += p;
     ys += yv;
+  };
+  const size_t gtid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = vec_ok ? count / 4 : 0;          // 16-byte loads when both tensors are 16-byte aligned
+  for (size_t i = gtid; i < n4; i += stride) {
+    const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(x + 4 * i), yv = *reinterpret_cast<const f32x4_t*>(y + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) term(xv[e], yv[e]);
   }
+  for (size_t i = n4 * 4 + gtid; i < count; i += stride) term(x[i], y[i]);
   __shared__ double red[4][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double a = wave_sum_d((double)bce), b = wave_sum_d((double)py), c = wave_sum_d((double)ps), d = wave_sum_d((double)ys);
@@ -1056,7 +1091,8 @@ extern "C" int vk_bce_dice_loss(size_t count, const float* logits, const float* 
   hipStream_t st = (hipStream_t)stream;
   vkh::ProfScope ps_("bce_dice_loss", st, 0.0, (double)count * (dlogits ? 20.0 : 8.0));
   VK_CHECK_HIP(hipMemsetAsync(sums, 0, 8 * sizeof(double), st));
-  hipLaunchKernelGGL(k_loss_reduce, dim3(grid_for(count, 256, 1024)), dim3(256), 0, st, count, logits, target, sums);
+  const int vec_ok = (((uintptr_t)logits | (uintptr_t)target) & 15) == 0 ? 1 : 0;
+  hipLaunchKernelGGL(k_loss_reduce, dim3(grid_for(vec_ok ? (count + 3) / 4 : count, 256, 2048)), dim3(256), 0, st, count, logits, target, sums, vec_ok);
   hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, (double)count, sums, loss_out, w_bce, w_dice);
   if (dlogits) hipLaunchKernelGGL(k_loss_bwd, dim3(grid_for(count)), dim3(256), 0, st, count, logits, target, sums, grad_scale, dlogits);
   VK_CHECK_HIP(hipGetLastError());
