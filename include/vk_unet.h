@@ -229,10 +229,11 @@ typedef struct {
 
 int vk_unet_create(const vk_unet_config* cfg, vk_unet** out);
 void vk_unet_destroy(vk_unet* h);
-/* A training plan runs its weight-gradient kernels on a second, library-owned HIP stream beside the caller's stream (fork per
- * layer once dz is final, join at the end of every backward stage, before the stage's gradient bucket may be read); the only
- * host-side state the library keeps.  enable = 0 puts them back on the caller's stream (the Python host does that when a
- * gradient reducer is attached: with RCCL's stream as a third party the split measured slower).  Default: on. */
+/* Optional: run a training plan's weight-gradient kernels on a second, library-owned HIP stream beside the caller's stream
+ * (fork per layer once dz is final, join at the end of every backward stage, before the stage's gradient bucket may be
+ * read); the only host-side state the library keeps.  Measured +1.3 % step throughput on one GPU, but the overlapping
+ * kernels slow each other (per-kernel durations grow by 30-90 %), and with RCCL's stream as a third party the split measured
+ * slower — so it is OFF by default (enable = 1, or VK_SIDE_STREAM=1 in the environment, turns it on). */
 int vk_unet_set_side_stream(vk_unet* h, int enable);
 int vk_unet_num_tensors(const vk_unet* h);
 int vk_unet_tensor_info(const vk_unet* h, int index, vk_tensor_info* out);

@@ -304,7 +304,9 @@ struct vk_unet {
   bool bound = false;
   // Weight gradients only feed the optimizer, so they run on a second (library-owned) stream beside the chain
   // dgrad -> BN backward -> dgrad ... of the caller's stream: fork event after the layer's dz is final, join at the end of every
-  // backward stage (before the caller may all-reduce / read that stage's gradient bucket).  VK_NO_SIDE_STREAM=1 disables it.
+  // backward stage (before the caller may all-reduce / read that stage's gradient bucket).  Opt-in (vk_unet_set_side_stream or
+  // VK_SIDE_STREAM=1): the step gets 1.3 % faster, but kernels that share the chip each run longer, which makes every per-kernel
+  // duration (rocprofv3, bench.py's roofline) a statement about the overlap instead of about the kernel.
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_dirty = false;
@@ -737,7 +739,7 @@ extern "C" int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_b
   if (!h->halo_tab.empty())
     VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_halo, h->halo_tab.data(), h->halo_tab.size() * sizeof(HaloPackEntry), hipMemcpyHostToDevice));
   VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_bn, h->bn_tab.data(), h->bn_tab.size() * sizeof(BnEvalEntry), hipMemcpyHostToDevice));
-  if (h->cfg.training && !h->side && !getenv("VK_NO_SIDE_STREAM")) RET_IF(vk_unet_set_side_stream(h, 1));
+  if (h->cfg.training && !h->side && getenv("VK_SIDE_STREAM")) RET_IF(vk_unet_set_side_stream(h, 1));
   h->bound = true;
   return VK_OK;
 }
