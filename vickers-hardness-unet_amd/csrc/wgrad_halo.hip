@@ -94,8 +94,11 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
     sh[j] = affine ? sd.shift[cl0 + vvec * VE + j] : 0.f;
   }
 
-  u32x4_t zreg[ZPASS], vreg[VPASS];
-  uint32_t vmask = 0;
+  // staging registers: one set (tile t+1 in flight under the MFMAs of tile t) or, in the small-channel WS configurations whose
+  // tiles are a few MFMAs long, two sets (tiles t+1 and t+2 in flight: an HBM round trip is longer than one tile's work)
+  constexpr int DEPTH = (WS || KT <= 32) ? 2 : 1;
+  u32x4_t zreg[DEPTH][ZPASS], vreg[DEPTH][VPASS];
+  uint32_t vmask[DEPTH] = {};
 
   // ---- per-thread staging geometry relative to the tile origin, computed once
   int z_rel[ZPASS], z_yx[ZPASS];                 // element offset (py*W + px)*K + k, packed (py << 8 | px), -1 = unused slot
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
     v_yx[i] = ok ? ((hy << 8) | hx) : -1;
   }
 
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int t, u32x4_t (&zreg)[ZPASS], u32x4_t (&vreg)[VPASS], uint32_t& vmask) {
     int tt = t;
     const int tx = tt % p.tiles_x;
     tt /= p.tiles_x;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
     }
   };
 
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](int stage, const u32x4_t (&zreg)[ZPASS], const u32x4_t (&vreg)[VPASS], uint32_t vmask) {
     char* Zs = smem + stage * STAGE;
     char* Vs = Zs + PX * ZSB;
 #pragma unroll
@@ -258,17 +261,20 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
   };
 
   // ---- stream over this workgroup's pixel tiles: t = blockIdx.z, + splits, ...
+  const int dbg = p.dbg_skip_epilogue >> 1;     // timing experiments (VK_WH_DBG, results WRONG): 1 no tile loads, 2 no LDS tile stores, 4 no MFMA steps, 8 no barriers
   int t = blockIdx.z;
   if (t < p.ntiles) {
-    load_tile(t);
-    store_tile(0);
+    load_tile(t, zreg[0], vreg[0], vmask[0]);
+    store_tile(0, zreg[0], vreg[0], vmask[0]);
   }
+  if (DEPTH == 2 && t + p.splits < p.ntiles) load_tile(t + p.splits, zreg[0], vreg[0], vmask[0]);     // tile 1 -> set 0
   __syncthreads();
-  int it = 0;
-  const int dbg = p.dbg_skip_epilogue >> 1;     // timing experiments (VK_WH_DBG, results WRONG): 1 no tile loads, 2 no LDS tile stores, 4 no MFMA steps, 8 no barriers
-  for (; t < p.ntiles; t += p.splits, ++it) {
+  auto iteration = [&](int it, u32x4_t (&zl)[ZPASS], u32x4_t (&vl)[VPASS], uint32_t& ml, const u32x4_t (&zs)[ZPASS],
+                       const u32x4_t (&vs)[VPASS], const uint32_t& ms) {
+    // loads go into set (zl, vl); the set (zs, vs) — requested one (DEPTH 2) or zero (DEPTH 1: same set) iterations ago — is stored
     const bool more = t + p.splits < p.ntiles;
-    if (more && !(dbg & 1)) load_tile(t + p.splits);
+    const int tl = t + DEPTH * p.splits;
+    if (tl < p.ntiles && !(dbg & 1)) load_tile(tl, zl, vl, ml);
     const char* Zs = smem + (it & 1) * STAGE;
     const char* Vs = Zs + PX * ZSB;
     if (!(dbg & 4)) {
@@ -279,8 +285,20 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
         for (int ks = 0; ks < 4; ++ks) compute_step(Zs, Vs, ks);
       }
     }
-    if (more && !(dbg & 2)) store_tile((it + 1) & 1);
+    if (more && !(dbg & 2)) store_tile((it + 1) & 1, zs, vs, ms);
     if (!(dbg & 8)) __syncthreads();
+  };
+  for (int it = 0; t < p.ntiles; t += p.splits, ++it) {
+    if (DEPTH == 1) {
+      iteration(it, zreg[0], vreg[0], vmask[0], zreg[0], vreg[0], vmask[0]);
+    } else {
+      // even iterations: tile t+2 -> set 1, tile t+1 (set 0) -> LDS; odd iterations the other way round
+      iteration(it, zreg[DEPTH - 1], vreg[DEPTH - 1], vmask[DEPTH - 1], zreg[0], vreg[0], vmask[0]);
+      t += p.splits;
+      ++it;
+      if (t >= p.ntiles) break;
+      iteration(it, zreg[0], vreg[0], vmask[0], zreg[DEPTH - 1], vreg[DEPTH - 1], vmask[DEPTH - 1]);
+    }
   }
 
   // ---- epilogue
