@@ -1,3 +1,5 @@
+# bench.py default line + rocprofv3 kernel stats + PMC HBM-traffic passes on a gpurun box:  gpurun --timeout 1200 -- 'bash tools/gpu_profile.sh'
+# then copy gpurun_out/prof3/runc/*_kernel_stats.csv, gpurun_out/traffic3.json and the bench line into profiles/
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 ( time timeout -k 10 500 python bench.py ) > gpurun_out/bench_default.log 2>&1
