@@ -927,7 +927,9 @@ static int col_select(const HaloParams& p, hipStream_t st) {
   if (p.K >= 128) {
     const long kt = (p.K + 127) / 128;
     if (alt == 1) return launch_col<T, 16, 128, 2, 2, true, 1>(p, st);
-    if (alt == 3 || (alt != 2 && tiles16 * kt < 256)) return launch_col<T, 8, 128, 2, 2, false, 2>(p, st);
+    // too few 16x16 tiles to fill the chip, or a reduction of one or two channel chunks (the concat gradients of decoder
+    // blocks 2/3: HBM / epilogue-bound, measured equal on both tiles): the 4-wave 8x16x128 tile, two workgroups per CU
+    if (alt == 3 || (alt != 2 && (tiles16 * kt < 256 || p.nchunks <= 2))) return launch_col<T, 8, 128, 2, 2, false, 2>(p, st);
     return launch_col<T, 16, 128, 4, 2, true, 2>(p, st);                    // 8 waves, 4 rows x 64 channels per wave
   }
   if (p.K >= 64) return launch_col<T, 16, 64, 4, 1, false, 2>(p, st);
