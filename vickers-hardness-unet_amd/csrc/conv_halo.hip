@@ -190,9 +190,22 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
       const int row = e_row + ps * ERPP;          // tile pixel index
       const int y = y0 + (row >> 4), x = x0 + (row & 15);
       if (y < p.H && x < p.W && col_ok) {
+        const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(smem + row * ESB + e_vec * 16);
+        const size_t eoff = (((size_t)n * p.H + y) * p.W + x) * ld + colx;
         float f[VE];
-        Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(smem + row * ESB + e_vec * 16), f);
-        finish(f, (((size_t)n * p.H + y) * p.W + x) * ld + colx);
+        if (p.accumulate || bnr) {
+          Vec16<T>::unpack(raw, f);
+          finish(f, eoff);
+        } else {
+          // plain store: the LDS tile already holds the rounded values, so they go out as they are (no pack / unpack round
+          // trip) and only a launch that wants BN statistics pays for the sums
+          if (p.stats) {
+            Vec16<T>::unpack(raw, f);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
+          }
+          *reinterpret_cast<u32x4_t*>(yb + eoff * EB) = raw;
+        }
       }
     }
   }
