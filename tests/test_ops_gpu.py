@@ -228,7 +228,10 @@ def test_stem_fwd(dtn):
 DGRAD_CASES = [
     ("s1_3x3", 2, 24, 64, 64, 3, 1, 1),
     ("s2_3x3", 2, 24, 64, 128, 3, 2, 1),
+    ("s2_3x3_parity_tiles", 2, 32, 64, 128, 3, 2, 1),      # 16x16 pixels per parity class = whole 128-pixel tiles: tap skipping active
+    ("s2_3x3_c256", 1, 64, 128, 256, 3, 2, 1),
     ("s2_1x1", 2, 24, 64, 128, 1, 2, 0),
+    ("s2_1x1_parity_tiles", 2, 32, 64, 128, 1, 2, 0),
     ("k16", 1, 40, 32, 16, 3, 1, 1),      # reduction over 16 output channels (small-C mode)
     ("k32", 1, 40, 128, 32, 3, 1, 1),
     ("c128", 2, 24, 128, 128, 3, 1, 1),

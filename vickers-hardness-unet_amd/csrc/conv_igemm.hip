@@ -41,6 +41,11 @@ struct ConvParams {
   int N, H, W, Ho, Wo, K, R, S, slog, pad, transposed, accumulate;
   int C, M, RS, RSC, nchunks, log2C;
   FastDiv div_hw, div_w, div_s;
+  // stride-2 data gradient (3x3): output pixels are enumerated parity class by parity class — (h & 1, w & 1) selects which of
+  // the 9 taps can contribute at all (1, 2, 2 or 4 of them) — so a tile of one class walks only those taps instead of
+  // zero-filling 3/4 of its operand rows: `parity` = pixels per class and image (0: plain row-major enumeration)
+  int parity;
+  FastDiv div_q, div_w2;
 };
 
 constexpr int kBK = 32;
@@ -95,14 +100,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int a_row = tid / VPR, a_vec = tid % VPR;
   int a_n[APASS], a_h0[APASS], a_w0[APASS];
   const int HoWo = p.Ho * p.Wo;
+  // m -> (image, row, column); in parity order: m = ((n * 4 + class) * Q + yy * (Wo / 2) + xx), pixel (2 yy + ph, 2 xx + pw)
+  auto decode = [&](int m, int& n, int& pp, int& q) {
+    n = (int)fdiv((uint32_t)m, p.div_hw);
+    const int rem = m - n * HoWo;
+    if (p.parity) {
+      const int cls = (int)fdiv((uint32_t)rem, p.div_q);
+      const int r2 = rem - cls * p.parity;
+      const int yy = (int)fdiv((uint32_t)r2, p.div_w2);
+      const int xx = r2 - yy * (p.Wo >> 1);
+      pp = 2 * yy + (cls >> 1);
+      q = 2 * xx + (cls & 1);
+    } else {
+      pp = (int)fdiv((uint32_t)rem, p.div_w);
+      q = rem - pp * p.Wo;
+    }
+  };
+  // taps this tile has to walk: all of them, or (parity order, tile inside one class) those with r = ph + pad, s = pw + pad mod 2
+  int tap_vr = -1, tap_vs = -1, nch = p.nchunks;
+  if (p.parity && p.parity % BM == 0) {
+    const int cls = (m0 % HoWo) / p.parity;
+    tap_vr = ((cls >> 1) + p.pad) & 1;
+    tap_vs = ((cls & 1) + p.pad) & 1;
+    const int nr = (p.R + 1 - tap_vr) / 2, ns = (p.S + 1 - tap_vs) / 2;      // taps 0..R-1 of that parity
+    nch = nr * ns * (p.C / kBK);
+  }
+  auto tap_valid = [&](int r, int s) { return tap_vr < 0 || ((((r ^ tap_vr) | (s ^ tap_vs)) & 1) == 0); };
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
     const int m = m0 + a_row + i * RPP;
     if (m < p.M) {
-      const int n = (int)fdiv((uint32_t)m, p.div_hw);
-      const int rem = m - n * HoWo;
-      const int pp = (int)fdiv((uint32_t)rem, p.div_w);
-      const int q = rem - pp * p.Wo;
+      int n, pp, q;
+      decode(m, n, pp, q);
       a_n[i] = n;
       if (MODE == 2) {
         a_h0[i] = 2 * pp - 3;
@@ -202,11 +231,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         load_a_src(p.s1, rs1, c - p.s0.C, ld_r, ld_s, true);
       }
       load_b(ld_tap * p.C + c);
-      // advance
-      ++ld_s;
-      ++ld_tap;
-      if (ld_s == p.S) { ld_s = 0; ++ld_r; }
-      if (ld_tap == p.RS) { ld_tap = 0; ld_r = 0; ld_s = 0; ++ld_cc; }
+      // advance to the next tap this tile walks
+      do {
+        ++ld_s;
+        ++ld_tap;
+        if (ld_s == p.S) { ld_s = 0; ++ld_r; }
+        if (ld_tap == p.RS) { ld_tap = 0; ld_r = 0; ld_s = 0; ++ld_cc; }
+      } while (!tap_valid(ld_r, ld_s));
     } else if (MODE == 1) {
       const int kelem = ld_kc * kBK + a_vec * VE;
       const int tap = kelem >> p.log2C;
@@ -302,11 +333,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   };
 
   // ---- main loop: register-staged double buffer, one barrier per 32-deep K chunk ----
-  load_chunk();
-  store_chunk(0);
+  if (nch == 0 && p.accumulate) return;   // a parity class no tap reaches (1x1 stride 2: three of the four): nothing to add
+  if (MODE == 0 && nch > 0) {
+    while (!tap_valid(ld_r, ld_s)) {      // first tap of this tile's parity class
+      ++ld_s;
+      ++ld_tap;
+      if (ld_s == p.S) { ld_s = 0; ++ld_r; }
+    }
+  }
+  if (nch > 0) {
+    load_chunk();
+    store_chunk(0);
+  }
   __syncthreads();
-  for (int kc = 0; kc < p.nchunks; ++kc) {
-    const bool more = kc + 1 < p.nchunks;
+  for (int kc = 0; kc < nch; ++kc) {
+    const bool more = kc + 1 < nch;
     if (more) load_chunk();
     compute(kc & 1);
     if (more) store_chunk((kc + 1) & 1);
@@ -348,7 +389,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int m = m0 + row;
     if (m < p.M && col_ok) {
       u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + row * ESB + e_vec * 16);
-      u32x4_t* gp = reinterpret_cast<u32x4_t*>(yb + ((size_t)m * ld + colx) * EB);
+      size_t mm = (size_t)m;                    // linear NHWC pixel index of this row
+      if (p.parity) {
+        int n, pp, q;
+        decode(m, n, pp, q);
+        mm = ((size_t)n * p.Ho + pp) * p.Wo + q;
+      }
+      u32x4_t* gp = reinterpret_cast<u32x4_t*>(yb + (mm * ld + colx) * EB);
       float f[VE];
       Vec16<T>::unpack(v, f);
       if (p.accumulate) {
@@ -545,6 +592,15 @@ int conv_fwd_impl(const vk_conv_desc* d, const void* w, int packed, void* y, voi
   p.div_hw = vkh::make_fastdiv((uint32_t)(d->Ho * d->Wo));
   p.div_w = vkh::make_fastdiv((uint32_t)d->Wo);
   p.div_s = vkh::make_fastdiv((uint32_t)d->S);
+  p.parity = 0;
+  p.div_q = p.div_w2 = vkh::make_fastdiv(1);
+  if (mode == 0 && d->transposed && d->stride == 2 && ((d->R == 3 && d->S == 3 && d->pad == 1) || (d->R == 1 && d->S == 1 && d->pad == 0)) &&
+      d->Ho % 2 == 0 && d->Wo % 2 == 0 && C % kBK == 0 &&
+      !getenv("VK_IGEMM_NO_PARITY")) {
+    p.parity = (d->Ho / 2) * (d->Wo / 2);
+    p.div_q = vkh::make_fastdiv((uint32_t)p.parity);
+    p.div_w2 = vkh::make_fastdiv((uint32_t)(d->Wo / 2));
+  }
   VK_CHECK_ARG((size_t)d->N * d->Ho * d->Wo < (1ull << 31), "vk_conv_fwd: too many output pixels");
   return dispatch(d->dtype, p, mode, st);
 }
@@ -572,6 +628,8 @@ int stem_fwd_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void* 
   p.div_hw = vkh::make_fastdiv((uint32_t)(p.Ho * p.Wo));
   p.div_w = vkh::make_fastdiv((uint32_t)p.Wo);
   p.div_s = vkh::make_fastdiv(1);
+  p.parity = 0;
+  p.div_q = p.div_w2 = vkh::make_fastdiv(1);
   return dispatch(dt, p, 2, st);
 }
 
