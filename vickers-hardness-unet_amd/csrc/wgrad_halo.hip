@@ -188,7 +188,11 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
   const int lane_v = (4 * (lane >> 4) + ((lane & 15) >> 2)) * VSB + (wc0 + 4 * (lane & 3)) * 2;
 
   // one 32-pixel reduction step = tile rows (2*ks, 2*ks+1)
-  auto compute_step = [&](const char* Zs, const char* Vs, int ks) {
+  // hsel: 0 = all nine taps (no tap split), 1 = taps 0-4, 2 = taps 5-8.  Compile-time, chosen ONCE outside the tile loop, so that
+  // the four 32-pixel steps of a tile form one basic block and the fragment reads of step k+1 can be scheduled under the MFMAs
+  // of step k (a wave-uniform branch inside every step cut the schedule into four blocks, each with its own read-latency bubble)
+  auto compute_step = [&](const char* Zs, const char* Vs, int ks, auto hsel_c) {
+    constexpr int HSEL = decltype(hsel_c)::value;
     if (EB == 2) {
       const char* const Zl = Zs + lane_z;      // fragment reads are lane base + immediate
       const char* const Vl = Vs + lane_v;
@@ -224,8 +228,8 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
             for (int b = 0; b < TCc; ++b) acc[t][a][b] = Mma<T>::run(zf[a], vf[b], acc[t][a][b]);
         }
       };
-      if (!TS) taps16(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
-      else if (half == 0) taps16(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+      if constexpr (HSEL == 0) taps16(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+      else if constexpr (HSEL == 1) taps16(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
       else taps16(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
     } else {
       const int i = lane & 15, kg = lane >> 4;
@@ -253,8 +257,8 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
                 acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[a], vf[b], acc[t][a][b], 0, 0, 0);
           }
         };
-        if (!TS) taps32(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
-        else if (half == 0) taps32(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+        if constexpr (HSEL == 0) taps32(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+        else if constexpr (HSEL == 1) taps32(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
         else taps32(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
       }
     }
@@ -269,37 +273,42 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
   }
   if (DEPTH == 2 && t + p.splits < p.ntiles) load_tile(t + p.splits, zreg[0], vreg[0], vmask[0]);     // tile 1 -> set 0
   __syncthreads();
-  auto iteration = [&](int it, u32x4_t (&zl)[ZPASS], u32x4_t (&vl)[VPASS], uint32_t& ml, const u32x4_t (&zs)[ZPASS],
-                       const u32x4_t (&vs)[VPASS], const uint32_t& ms) {
-    // loads go into set (zl, vl); the set (zs, vs) — requested one (DEPTH 2) or zero (DEPTH 1: same set) iterations ago — is stored
-    const bool more = t + p.splits < p.ntiles;
-    const int tl = t + DEPTH * p.splits;
-    if (tl < p.ntiles && !(dbg & 1)) load_tile(tl, zl, vl, ml);
-    const char* Zs = smem + (it & 1) * STAGE;
-    const char* Vs = Zs + PX * ZSB;
-    if (!(dbg & 4)) {
-      if (WS) {
-        compute_step(Zs, Vs, wave);
-      } else {
+  auto tile_loop = [&](auto hsel_c) {
+    auto iteration = [&](int it, u32x4_t (&zl)[ZPASS], u32x4_t (&vl)[VPASS], uint32_t& ml, const u32x4_t (&zs)[ZPASS],
+                         const u32x4_t (&vs)[VPASS], const uint32_t& ms) {
+      // loads go into set (zl, vl); the set (zs, vs) — requested one (DEPTH 2) or zero (DEPTH 1: same set) iterations ago — is stored
+      const bool more = t + p.splits < p.ntiles;
+      const int tl = t + DEPTH * p.splits;
+      if (tl < p.ntiles && !(dbg & 1)) load_tile(tl, zl, vl, ml);
+      const char* Zs = smem + (it & 1) * STAGE;
+      const char* Vs = Zs + PX * ZSB;
+      if (!(dbg & 4)) {
+        if (WS) {
+          compute_step(Zs, Vs, wave, hsel_c);
+        } else {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) compute_step(Zs, Vs, ks);
+          for (int ks = 0; ks < 4; ++ks) compute_step(Zs, Vs, ks, hsel_c);
+        }
+      }
+      if (more && !(dbg & 2)) store_tile((it + 1) & 1, zs, vs, ms);
+      if (!(dbg & 8)) __syncthreads();
+    };
+    for (int it = 0; t < p.ntiles; t += p.splits, ++it) {
+      if (DEPTH == 1) {
+        iteration(it, zreg[0], vreg[0], vmask[0], zreg[0], vreg[0], vmask[0]);
+      } else {
+        // even iterations: tile t+2 -> set 1, tile t+1 (set 0) -> LDS; odd iterations the other way round
+        iteration(it, zreg[DEPTH - 1], vreg[DEPTH - 1], vmask[DEPTH - 1], zreg[0], vreg[0], vmask[0]);
+        t += p.splits;
+        ++it;
+        if (t >= p.ntiles) break;
+        iteration(it, zreg[0], vreg[0], vmask[0], zreg[DEPTH - 1], vreg[DEPTH - 1], vmask[DEPTH - 1]);
       }
     }
-    if (more && !(dbg & 2)) store_tile((it + 1) & 1, zs, vs, ms);
-    if (!(dbg & 8)) __syncthreads();
   };
-  for (int it = 0; t < p.ntiles; t += p.splits, ++it) {
-    if (DEPTH == 1) {
-      iteration(it, zreg[0], vreg[0], vmask[0], zreg[0], vreg[0], vmask[0]);
-    } else {
-      // even iterations: tile t+2 -> set 1, tile t+1 (set 0) -> LDS; odd iterations the other way round
-      iteration(it, zreg[DEPTH - 1], vreg[DEPTH - 1], vmask[DEPTH - 1], zreg[0], vreg[0], vmask[0]);
-      t += p.splits;
-      ++it;
-      if (t >= p.ntiles) break;
-      iteration(it, zreg[0], vreg[0], vmask[0], zreg[DEPTH - 1], vreg[DEPTH - 1], vmask[DEPTH - 1]);
-    }
-  }
+  if (!TS) tile_loop(std::integral_constant<int, 0>{});
+  else if (half == 0) tile_loop(std::integral_constant<int, 1>{});
+  else tile_loop(std::integral_constant<int, 2>{});
 
   // ---- epilogue
   if (p.dbg_skip_epilogue & 1) {
