@@ -931,7 +931,8 @@ static int launch_col(HaloParams p, hipStream_t st) {
 }
 
 // tile selection for the column-staged kernels.  VK_COL_ALT (diagnostic / tests) forces a shape of the K >= 128 class:
-//   1: 4 waves, 16x16x128, 8 rows x 64 channels per wave (one wave per SIMD);  2: the 8-wave 16x16x128 tile;  3: the 4-wave 8x16x128 tile
+//   1: 4 waves, 16x16x128, 8 rows x 64 channels per wave (one wave per SIMD);  2: the 8-wave 16x16x128 tile;  3: the 4-wave 8x16x128 tile;
+//   7: the 8-wave 8x16x128 tile
 template <typename T>
 static int col_select(const HaloParams& p, hipStream_t st) {
   const char* alt_s = getenv("VK_COL_ALT");
@@ -940,9 +941,12 @@ static int col_select(const HaloParams& p, hipStream_t st) {
   if (p.K >= 128) {
     const long kt = (p.K + 127) / 128;
     if (alt == 1) return launch_col<T, 16, 128, 2, 2, true, 1>(p, st);
-    // too few 16x16 tiles to fill the chip, or a reduction of one or two channel chunks (the concat gradients of decoder
-    // blocks 2/3: HBM / epilogue-bound, measured equal on both tiles): the 4-wave 8x16x128 tile, two workgroups per CU
-    if (alt == 3 || (alt != 2 && (tiles16 * kt < 256 || p.nchunks <= 2))) return launch_col<T, 8, 128, 2, 2, false, 2>(p, st);
+    // a reduction of one or two channel chunks (the concat gradients of decoder blocks 2/3: HBM / epilogue-bound, thousands of
+    // tiles): the 4-wave 8x16x128 tile, two workgroups per CU
+    if (alt == 3 || (alt != 2 && alt != 7 && p.nchunks <= 2)) return launch_col<T, 8, 128, 2, 2, false, 2>(p, st);
+    // too few 16x16 tiles to fill the chip (layer4: 256 workgroups of 8x16x128): the same tile on EIGHT waves (4 rows x 32
+    // channels each) — one workgroup per CU either way, but two waves per SIMD instead of one (L4 dgrad 46.6 -> 41.3 us)
+    if (alt == 7 || (alt != 2 && tiles16 * kt < 256)) return launch_col<T, 8, 128, 2, 4, true, 2>(p, st);
     return launch_col<T, 16, 128, 4, 2, true, 2>(p, st);                    // 8 waves, 4 rows x 64 channels per wave
   }
   if (p.K >= 64) return launch_col<T, 16, 64, 4, 1, false, 2>(p, st);
