@@ -13,6 +13,10 @@
  *   vk_amp_check_inf .......................... GradScaler inf check          train.py:443-445 (610-611)
  *   vk_conv_fwd / vk_conv_wgrad / ... ......... the ATen operators the reference dispatches to
  *                                               (conv2d, batch_norm, relu, max_pool2d, interpolate, cat)
+ *   vk_letterbox_preprocess ................... letterbox + BGR->RGB + normalise   infer_pth_gui.py:17-24, 46-49;
+ *                                               ui_infer_quadrilateral.py:197-216, 662-678; ui_infer_rectangle.py:225-245, 520-535
+ *   vk_letterbox_postprocess_mask ............. sigmoid, threshold, un-letterbox  infer_pth_gui.py:26-29, 50-53
+ *   vk_letterbox_postprocess_prob ............. sigmoid, un-letterbox, clip       ui_infer_quadrilateral.py:219-231, 705-711
  *
  * Conventions
  *   - plain pointers and sizes only; no C++/torch types cross this boundary.
@@ -138,6 +142,29 @@ int vk_stem_fwd(vk_dtype dtype, int N, int H, int W, const void* x4, const void*
 #define VK_WGRAD_WORKSPACE_BYTES (64u << 20)
 int vk_conv_wgrad(const vk_conv_desc* d, const void* dz, float* dw, void* workspace, size_t workspace_bytes, void* stream);
 int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const void* dz, float* dw_krsc3, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The steps either side of model(x) in the inference wrappers, one fused pass each.
+ * The caller decides the geometry (the reference has two conventions: image in the top-left corner with
+ * scale = min(S/h, S/w), infer_pth_gui.py:17-24; image centred with scale = min(S/max(h,w), 1),
+ * ui_infer_quadrilateral.py:197-216) and passes it in the descriptor; the library does the pixel work with
+ * cv2.resize's arithmetic (8-bit INTER_LINEAR in 11-bit fixed point, float INTER_LINEAR, INTER_NEAREST).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int h, w;             /* original image size */
+  int src_stride;       /* bytes per row of the original BGR image (>= 3*w); unused by the post-processing calls */
+  int size;             /* side S of the square network input / logit map */
+  int nh, nw;           /* size of the resized image inside the square */
+  int top, left;        /* its position inside the square */
+  int pad_value;        /* border value 0..255, applied before the normalisation */
+} vk_letterbox_desc;
+
+/* uint8 BGR [h][w][3] (device) -> float32 [3][S][S] RGB planes, ((v/255) - mean) / std with the ImageNet constants */
+int vk_letterbox_preprocess(const vk_letterbox_desc* d, const uint8_t* bgr, float* x_nchw, void* stream);
+/* logits [S][S] -> uint8 [h][w] in {0,255}: (sigmoid >= thresh), crop, INTER_NEAREST back to the original size */
+int vk_letterbox_postprocess_mask(const vk_letterbox_desc* d, const float* logits, float thresh, uint8_t* mask_hw, void* stream);
+/* logits [S][S] -> float32 [h][w] in [0,1]: sigmoid, crop, INTER_LINEAR back to the original size (copy when equal), clip */
+int vk_letterbox_postprocess_prob(const vk_letterbox_desc* d, const float* logits, float* prob_hw, void* stream);
 
 /* NCHW fp32 [N][3][H][W] -> NHWC4 `dtype` */
 int vk_input_transform(vk_dtype dtype, int N, int H, int W, const float* x, void* x4, void* stream);

@@ -1,0 +1,131 @@
+"""-m gpu: the fused pre/post-processing kernels against oracle/prepost_oracle.py.
+Pre-processing is integer + IEEE float arithmetic: bit-exact.  Post-processing passes through expf: masks may
+differ only where |sigmoid - thresh| is within rounding, probabilities within 2e-6."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prepost_oracle as P
+
+pytestmark = pytest.mark.gpu
+vk = importlib.import_module("vickers-hardness-unet_amd")
+DEV = "cuda:0"
+
+SHAPES = [(1200, 1600), (1600, 1200), (300, 400), (512, 512), (1024, 1024), (1001, 333), (37, 2048), (511, 513),
+          (256, 256), (3, 5), (1, 1), (2048, 2048), (700, 512)]
+
+
+def _image(h, w, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if h > 8 and w > 8:      # some smooth structure besides the noise
+        yy, xx = np.mgrid[0:h, 0:w]
+        base[..., 1] = ((yy * 3 + xx * 2) % 256).astype(np.uint8)
+    return base
+
+
+@pytest.mark.parametrize("conv", ["pad_br", "centered"])
+@pytest.mark.parametrize("h,w", SHAPES)
+@pytest.mark.parametrize("size", [512, 256])
+def test_preprocess_bit_exact(h, w, conv, size):
+    img = _image(h, w, h * 7 + w)
+    want, geo = P.preprocess(img, size, conv)
+    x, meta = vk.prepost.preprocess(img, size, conv, DEV)
+    assert meta[1][1:] == geo and meta[2] == (h, w)
+    got = x[0].cpu().numpy()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+def test_preprocess_batch_and_pad_value():
+    imgs = [_image(h, w, i) for i, (h, w) in enumerate([(600, 800), (512, 512), (90, 700)])]
+    x, metas = vk.prepost.preprocess_batch(imgs, 512, "centered", DEV)
+    assert x.shape == (3, 3, 512, 512)
+    for i, im in enumerate(imgs):
+        assert np.array_equal(x[i].cpu().numpy(), P.preprocess(im, 512, "centered")[0])
+    got, meta = vk.prepost.preprocess(imgs[2], 512, "centered", DEV, pad_value=114)
+    _, nh, nw, top, left = P.geometry_centered(90, 700, 512)
+    want = P.normalise_nchw(P.letterbox(imgs[2], 512, nh, nw, top, left, pad_value=114))
+    assert np.array_equal(got[0].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("conv", ["pad_br", "centered"])
+@pytest.mark.parametrize("h,w", SHAPES)
+def test_postprocess(h, w, conv):
+    size = 512
+    rng = np.random.default_rng(h + 3 * w)
+    lg = (rng.normal(size=(size, size)) * 3).astype(np.float32)
+    lg[::7, ::5] = 0.0                      # exactly on the threshold: sigmoid(0) = 0.5 >= 0.5
+    geo = (P.geometry_pad_br if conv == "pad_br" else P.geometry_centered)(h, w, size)
+    meta = (geo[0], geo, (h, w))
+    t = torch.from_numpy(lg).to(DEV)
+    m = vk.prepost.postprocess_mask(t, meta, 0.5).cpu().numpy()
+    want_m = P.postprocess_mask(lg, *geo[1:], (h, w), 0.5)
+    assert m.shape == want_m.shape and m.dtype == np.uint8
+    if not np.array_equal(m, want_m):
+        # only pixels whose sigmoid is within 1 ulp of the threshold may differ
+        src = P.resize_nearest(np.ascontiguousarray(lg[geo[3]:geo[3] + geo[1], geo[4]:geo[4] + geo[2]]), w, h)
+        assert np.abs(src[m != want_m]).max() < 1e-6
+    pr = vk.prepost.postprocess_prob(t, meta).cpu().numpy()
+    want_p = P.postprocess_prob(lg, *geo[1:], (h, w))
+    assert pr.shape == want_p.shape and pr.dtype == np.float32
+    assert np.abs(pr - want_p).max() <= 2e-6
+    # other thresholds of the reference's wrappers (ui_infer_quadrilateral.py:46 uses 0.45)
+    m45 = vk.prepost.postprocess_mask(t, meta, 0.45).cpu().numpy()
+    assert (m45 != P.postprocess_mask(lg, *geo[1:], (h, w), 0.45)).mean() < 1e-5
+
+
+def test_argument_errors():
+    L = vk._lib
+    import ctypes as C
+    x = torch.empty(3, 64, 64, device=DEV)
+    src = torch.zeros(10, 10, 3, dtype=torch.uint8, device=DEV)
+    bad = L.vk_letterbox_desc(10, 10, 30, 64, 70, 10, 0, 0, 0)          # nh > size
+    assert vk.lib().vk_letterbox_preprocess(C.byref(bad), src.data_ptr(), x.data_ptr(), None) == -1
+    assert b"does not fit" in vk.lib().vk_last_error_string()
+    bad = L.vk_letterbox_desc(10, 10, 20, 64, 10, 10, 0, 0, 0)          # stride below 3*w
+    assert vk.lib().vk_letterbox_preprocess(C.byref(bad), src.data_ptr(), x.data_ptr(), None) == -1
+    ok = L.vk_letterbox_desc(10, 10, 30, 64, 10, 10, 0, 0, 0)
+    assert vk.lib().vk_letterbox_preprocess(C.byref(ok), None, x.data_ptr(), None) == -1
+    with pytest.raises(ValueError):
+        vk.prepost.preprocess(np.zeros((4, 4), dtype=np.uint8), 64, "centered", DEV)
+
+
+@pytest.fixture(scope="module")
+def pair():
+    from oracle import unet_oracle as O
+    O.set_seed(7)
+    ref = O.build_model().eval()
+    O.set_seed(7)
+    model = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(DEV).eval()
+    return ref, model
+
+
+def test_wrappers_end_to_end(pair):
+    """predict_mask (infer_pth_gui.py:45-53) and Segmenter.infer (ui_infer_quadrilateral.py:680-711) against the
+    same pipelines assembled from the oracles (numpy pre/post + the CPU U-Net) at img_size 256."""
+    ref, model = pair
+    img = _image(300, 420, 5)
+    # probability map
+    seg = vk.prepost.Segmenter(model, img_size=256, device=DEV)
+    prob = seg.infer(img)
+    xo, geo = P.preprocess(img, 256, "centered")
+    with torch.no_grad():
+        lo = ref(torch.from_numpy(xo)[None])[0, 0].numpy()
+    want = P.postprocess_prob(lo, *geo, (300, 420))
+    assert prob.shape == (300, 420) and prob.dtype == np.float32
+    assert np.abs(prob - want).max() <= 1e-3          # logits agree to 1e-3 (fp32 tolerance of the path); sigmoid' <= 1/4
+    batch = seg.infer_batch([img, _image(200, 100, 6)])
+    assert np.abs(batch[0] - prob).max() <= 1e-5 and batch[1].shape == (200, 100)
+    # mask
+    mask = vk.prepost.predict_mask(model, img, DEV, img_size=256, thresh=0.5)
+    xo, geo = P.preprocess(img, 256, "pad_br")
+    with torch.no_grad():
+        lo = ref(torch.from_numpy(xo)[None])[0, 0].numpy()
+    want_m = P.postprocess_mask(lo, *geo, (300, 420), 0.5)
+    assert mask.shape == (300, 420) and mask.dtype == np.uint8
+    src = P.resize_nearest(np.ascontiguousarray(lo[:geo[0], :geo[1]]), 420, 300)
+    differ = mask != want_m
+    assert differ.mean() < 1e-3 and (not differ.any() or np.abs(src[differ]).max() <= 1e-3)

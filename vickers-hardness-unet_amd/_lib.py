@@ -35,6 +35,11 @@ class vk_bnr(C.Structure):
     _fields_ = [("z", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("sums", C.c_void_p)]
 
 
+class vk_letterbox_desc(C.Structure):
+    _fields_ = [("h", C.c_int), ("w", C.c_int), ("src_stride", C.c_int), ("size", C.c_int), ("nh", C.c_int),
+                ("nw", C.c_int), ("top", C.c_int), ("left", C.c_int), ("pad_value", C.c_int)]
+
+
 class vk_unet_config(C.Structure):
     _fields_ = [("N", C.c_int), ("size", C.c_int), ("dtype", C.c_int), ("training", C.c_int)]
 
@@ -65,6 +70,9 @@ SIGNATURES = {
     "vk_stem_fwd": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     "vk_conv_wgrad": (ci, [P(vk_conv_desc), vp, vp, vp, sz, vp]),
     "vk_stem_wgrad": (ci, [ci, ci, ci, ci, vp, vp, vp, vp]),
+    "vk_letterbox_preprocess": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
+    "vk_letterbox_postprocess_mask": (ci, [P(vk_letterbox_desc), vp, cf, vp, vp]),
+    "vk_letterbox_postprocess_prob": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
     "vk_input_transform": (ci, [ci, ci, ci, ci, vp, vp, vp]),
     "vk_bn_finalize": (ci, [ci, ci, vp, cd, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
     "vk_bn_relu_maxpool": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
