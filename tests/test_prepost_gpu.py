@@ -51,9 +51,14 @@ def test_preprocess_batch_and_pad_value():
     assert np.array_equal(got[0].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("kernel", ["per_pixel", "windowed", "auto"])
 @pytest.mark.parametrize("conv", ["pad_br", "centered"])
 @pytest.mark.parametrize("h,w", SHAPES)
-def test_postprocess(h, w, conv):
+def test_postprocess(h, w, conv, kernel, monkeypatch):
+    if kernel == "auto":
+        monkeypatch.delenv("VK_PP_WINDOW", raising=False)
+    else:
+        monkeypatch.setenv("VK_PP_WINDOW", "1" if kernel == "windowed" else "0")       # both kernels on every shape
     size = 512
     rng = np.random.default_rng(h + 3 * w)
     lg = (rng.normal(size=(size, size)) * 3).astype(np.float32)
