@@ -61,6 +61,31 @@ def test_load_state_dict_strict_and_dirty_tracking(vk, oracle):
         m.load_state_dict(bad, strict=True)
 
 
+def test_checkpoint_file_round_trip(vk, oracle, tmp_path):
+    """train.py:668-678 writes `torch.save(model.state_dict(), last.pth)`; infer_pth_gui.py:35-43 reads it back with
+    `torch.load(..., weights_only=True)` + `load_state_dict` (strict).  Both directions against the smp-keyed oracle
+    model, all 278 tensors bit-identical (the part that needs no real .pth)."""
+    oracle.set_seed(11)
+    ref = oracle.build_model()
+    m = vk.Unet(encoder_weights=None)
+    # reference-written checkpoint -> this package
+    torch.save(ref.state_dict(), tmp_path / "last.pth")
+    sd = torch.load(tmp_path / "last.pth", map_location="cpu", weights_only=True)
+    m.load_state_dict(sd)
+    for k, v in ref.state_dict().items():
+        assert torch.equal(m.state_dict()[k], v), k
+    # checkpoint written by this package -> reference model
+    torch.save(m.state_dict(), tmp_path / "best.pth")
+    sd2 = torch.load(tmp_path / "best.pth", map_location="cpu", weights_only=True)
+    assert list(sd2.keys()) == list(ref.state_dict().keys())
+    assert all(sd2[k].dtype == v.dtype and sd2[k].shape == v.shape for k, v in ref.state_dict().items())
+    oracle.set_seed(12)
+    other = oracle.build_model()
+    other.load_state_dict(sd2, strict=True)
+    for k, v in ref.state_dict().items():
+        assert torch.equal(other.state_dict()[k], v), k
+
+
 def test_constructor_rejects_what_the_reference_does_not_use(vk):
     with pytest.raises(vk.VkError):
         vk.Unet(encoder_weights="imagenet")          # needs a download
