@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--prof", action="store_true")
     ap.add_argument("--no-affine", action="store_true", help="sources without the BN+ReLU prologue (materialised activations)")
+    ap.add_argument("--no-stats", action="store_true", help="forward without the BatchNorm partial sums")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
     dev = torch.device("cuda:0")
@@ -64,6 +65,8 @@ def main():
         d_d = L_.vk_conv_desc(L_.dtype_code(dt), N, H, H, H, H, Ctot, 3, 3, 1, 1, 1,
                               L_.vk_src(dz.data_ptr(), K, 0, None, None, 0), L_.vk_src(None, 0, 0, None, None, 0))
         flops = 2.0 * N * H * H * K * 9 * Ctot
+        eb = 4 if dt == torch.float32 else 2
+        act_bytes = (sum(t.numel() for t, _, _ in ts) + N * H * H * K) * eb          # operands read / written once
 
         def weights(d, plain, rows, red):       # halo pack when the descriptor runs on the 3x3 tile kernels
             if not lib.vk_conv_uses_halo_pack(C.byref(d)):
@@ -74,7 +77,7 @@ def main():
         wf, fn_f = weights(d_f, w, K, Ctot)
         wd_, fn_d = weights(d_d, wt, Ctot, K)
         ops = {
-            "fwd": lambda: fn_f(C.byref(d_f), wf.data_ptr(), y.data_ptr(), None, 0, 0, stats.data_ptr(), st),
+            "fwd": lambda: fn_f(C.byref(d_f), wf.data_ptr(), y.data_ptr(), None, 0, 0, None if a.no_stats else stats.data_ptr(), st),
             "dgrad": lambda: fn_d(C.byref(d_d), wd_.data_ptr(), dx.data_ptr(), None, 0, 0, None, st),
             "wgrad": lambda: lib.vk_conv_wgrad(C.byref(d_f), dz.data_ptr(), dw.data_ptr(), wsl.data_ptr(), wsl.numel(), st),
         }
@@ -98,7 +101,7 @@ def main():
                 lib.vk_prof_enable(0)
                 for k, v in L_.prof_collect().items():
                     print(f"        {k:40s} {v['ms'] / v['n'] * 1e3:9.1f} us/launch")
-            print(f"{name:5s} {op:6s} H{H:<4d} C{Ctot:<4d} K{K:<4d} {us:9.1f} us  {flops / us / 1e6:8.1f} TF  ({flops / us / 1e6 / 2500 * 100:5.1f} % of MFMA peak)", flush=True)
+            print(f"{name:5s} {op:6s} H{H:<4d} C{Ctot:<4d} K{K:<4d} {us:9.1f} us  {flops / us / 1e6:8.1f} TF  ({flops / us / 1e6 / 2500 * 100:5.1f} % of MFMA peak)  {act_bytes / us / 1e3:7.0f} GB/s", flush=True)
 
 
 if __name__ == "__main__":

@@ -78,13 +78,20 @@ struct HaloCfg {
   static constexpr int EPASS = BM / ERPP;
   static constexpr int RED_OFF = BM * ESB;
   static constexpr int MAIN = A_BYTES + 2 * B_BYTES;
-  static constexpr int EPI = RED_OFF + 4 * BN * 2 * 4;
+  static constexpr int ESLOTS = (BN / VE > 16) ? 4 * 4 / (BN / VE / 16) : 4 * 4;
+  static constexpr int EPI = RED_OFF + ESLOTS * BN * 2 * 4;       // + [wave x 16-lane row][channel][2] partial sums
   static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
   static_assert(WGM * WGN == 4 && TH % WGM == 0 && BN % (16 * WGN) == 0, "wave layout");
   static_assert(EPASS >= 1, "epilogue mapping");
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
+
+// value of another lane of the same 16-lane row (DPP control word CTRL), at VALU rate
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 
 // ---- shared epilogue: accumulators -> LDS [tile pixel][channel] as T -> 16-byte NHWC stores
 //   * optional BN partial sums (sum / sum of squares of the stored values, fp64 atomics into replicated slabs)
@@ -214,27 +221,34 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
 #pragma unroll
       for (int j = 0; j < VE; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     }
+    // lanes holding the same channels sit EVPR apart.  Inside a 16-lane row they are added with DPP moves (VALU rate; the
+    // former ds_bpermute butterfly was 16 * log2(64 / EVPR) LDS-pipe instructions per thread and cost the 512x512 decoder
+    // layers a third of their time); the four rows of every wave go through LDS to the thread that owns the channel.
 #pragma unroll
     for (int j = 0; j < VE; ++j) {
-#pragma unroll
-      for (int o = EVPR; o < 64; o <<= 1) {
-        s1[j] += __shfl_xor(s1[j], o, 64);
-        s2[j] += __shfl_xor(s2[j], o, 64);
-      }
+      if (EVPR <= 1) { s1[j] += dpp_f<0xB1>(s1[j]); s2[j] += dpp_f<0xB1>(s2[j]); }       // quad_perm [1,0,3,2]
+      if (EVPR <= 2) { s1[j] += dpp_f<0x4E>(s1[j]); s2[j] += dpp_f<0x4E>(s2[j]); }       // quad_perm [2,3,0,1]
+      if (EVPR <= 4) { s1[j] += dpp_f<0x124>(s1[j]); s2[j] += dpp_f<0x124>(s2[j]); }     // row_ror:4
+      if (EVPR <= 8) { s1[j] += dpp_f<0x128>(s1[j]); s2[j] += dpp_f<0x128>(s2[j]); }     // row_ror:8
     }
     float* red = reinterpret_cast<float*>(smem + RED_OFF);
-    if (lane < EVPR) {
+    // slot = one full set of BN channel sums: a 16-lane row when it holds every vector of a tile row (EVPR <= 16), otherwise
+    // the EVPR / 16 neighbouring rows that hold them together (fp32, BN = 128)
+    constexpr int RPS = EVPR > 16 ? EVPR / 16 : 1, NSLOT = NW * 4 / RPS;
+    static_assert(EVPR <= 32, "partial-sum slots");
+    if (EVPR > 16 || li < EVPR) {
+      const int slot = (wave * 4 + kg) / RPS;
 #pragma unroll
       for (int j = 0; j < VE; ++j) {
-        red[(wave * BN + lane * VE + j) * 2 + 0] = s1[j];
-        red[(wave * BN + lane * VE + j) * 2 + 1] = s2[j];
+        red[(slot * BN + (lane % EVPR) * VE + j) * 2 + 0] = s1[j];
+        red[(slot * BN + (lane % EVPR) * VE + j) * 2 + 1] = s2[j];
       }
     }
     __syncthreads();
     if (tid < BN && n0 + tid < p.K) {
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      for (int w = 0; w < NSLOT; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
       if (p.bnr_sums) {
         const int kc = p.ld0;          // channel count of the first output part
         if (n0 + tid < kc) {
@@ -505,7 +519,8 @@ struct ColCfg {
   static constexpr int TP = TH / WGM, TC = BN / WGN / 16;
   static constexpr int ESB = BN * EB + 16;
   static constexpr int MAIN = NA * A_BYTES + 2 * B_BYTES;
-  static constexpr int EPI = BM * ESB + NW * BN * 2 * 4;
+  static constexpr int ESLOTS = (BN / VE > 16) ? NW * 4 / (BN / VE / 16) : NW * 4;
+  static constexpr int EPI = BM * ESB + ESLOTS * BN * 2 * 4;     // + [wave x 16-lane row][channel][2] partial sums
   static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
   static_assert(TH % WGM == 0 && BN % (16 * WGN) == 0 && (NW == 4 || NW == 8), "wave layout");
 };
@@ -725,7 +740,7 @@ struct C16Cfg {
   static constexpr int B_BYTES = BN * BS;
   static constexpr int TP = 4, TC = BN / 16;
   static constexpr int ESB = BN * 2 + 16;
-  static constexpr int EPI = 256 * ESB + 4 * BN * 2 * 4;
+  static constexpr int EPI = 256 * ESB + 4 * 4 * BN * 2 * 4;     // + [wave][16-lane row][channel][2] partial sums
   static constexpr int MAIN = A_BYTES + B_BYTES;
   static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
 };
