@@ -87,11 +87,6 @@ struct HaloCfg {
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 
-// value of another lane of the same 16-lane row (DPP control word CTRL), at VALU rate
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
 
 // ---- shared epilogue: accumulators -> LDS [tile pixel][channel] as T -> 16-byte NHWC stores
 //   * optional BN partial sums (sum / sum of squares of the stored values, fp64 atomics into replicated slabs)

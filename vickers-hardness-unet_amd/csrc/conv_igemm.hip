@@ -71,7 +71,8 @@ struct IgemmCfg {
   static constexpr int ERPP = 256 / EVPR;
   static constexpr int EPASS = BM / ERPP;
   static constexpr int RED_OFF = BM * ESB;
-  static constexpr int RED_BYTES = 4 * BN * 2 * 4;
+  static constexpr int ESLOTS = (EVPR > 16) ? 16 / (EVPR / 16) : 16;      // [wave x 16-lane row] sets of channel partial sums
+  static constexpr int RED_BYTES = ESLOTS * BN * 2 * 4;
   static constexpr int SMEM = (2 * STAGE > RED_OFF + RED_BYTES) ? 2 * STAGE : RED_OFF + RED_BYTES;
   static_assert(APASS >= 1 && TP >= 1 && TC >= 1, "tile too small");
   static_assert(EPASS >= 1, "epilogue mapping");
@@ -412,27 +413,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
   }
   if (p.stats) {
+    // same reduction as the tile kernels' epilogue (conv_halo.hip): DPP inside a 16-lane row, rows through LDS slots
 #pragma unroll
     for (int j = 0; j < VE; ++j) {
-#pragma unroll
-      for (int o = EVPR; o < 64; o <<= 1) {
-        s1[j] += __shfl_xor(s1[j], o, 64);
-        s2[j] += __shfl_xor(s2[j], o, 64);
-      }
+      if (EVPR <= 2) { s1[j] += dpp_f<0x4E>(s1[j]); s2[j] += dpp_f<0x4E>(s2[j]); }       // quad_perm [2,3,0,1]
+      if (EVPR <= 4) { s1[j] += dpp_f<0x124>(s1[j]); s2[j] += dpp_f<0x124>(s2[j]); }     // row_ror:4
+      if (EVPR <= 8) { s1[j] += dpp_f<0x128>(s1[j]); s2[j] += dpp_f<0x128>(s2[j]); }     // row_ror:8
     }
     float* red = reinterpret_cast<float*>(smem + Cfg::RED_OFF);
-    if (lane < EVPR) {
+    constexpr int RPS = EVPR > 16 ? EVPR / 16 : 1, NSLOT = 16 / RPS;
+    static_assert(EVPR >= 2 && EVPR <= 32, "partial-sum slots");
+    if (EVPR > 16 || (lane & 15) < EVPR) {
+      const int slot = (wave * 4 + (lane >> 4)) / RPS;
 #pragma unroll
       for (int j = 0; j < VE; ++j) {
-        red[(wave * BN + lane * VE + j) * 2 + 0] = s1[j];
-        red[(wave * BN + lane * VE + j) * 2 + 1] = s2[j];
+        red[(slot * BN + (lane % EVPR) * VE + j) * 2 + 0] = s1[j];
+        red[(slot * BN + (lane % EVPR) * VE + j) * 2 + 1] = s2[j];
       }
     }
     __syncthreads();
     if (tid < BN && n0 + tid < p.K) {
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      for (int w = 0; w < NSLOT; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
       double* sp = p.stats + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * p.K;
       atomicAdd(sp + n0 + tid, (double)a);
       atomicAdd(sp + p.K + n0 + tid, (double)b);

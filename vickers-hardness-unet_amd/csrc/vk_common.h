@@ -157,10 +157,24 @@ struct FastDiv {
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return d.div == 1 ? n : (__umulhi(n, d.mul) >> d.shr); }
 
 // ---------------------------------------------------------------- wave / block reductions
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// value of another lane through a DPP move (VALU rate; __shfl_xor is a ds_bpermute, i.e. an LDS-pipe instruction)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over the 16 lanes of each row, left in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);     // row_half_mirror
+  v += dpp_f<0x140>(v);     // row_mirror
   return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += dpp_f<0x142, 0xA>(v);      // row_bcast:15 -> rows 1 and 3 add the row before them
+  v += dpp_f<0x143, 0xC>(v);      // row_bcast:31 -> rows 2 and 3 add rows 0+1: lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
