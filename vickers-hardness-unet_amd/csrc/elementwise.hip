@@ -21,15 +21,19 @@ static inline int grid_for(size_t work_items, int block = 256, int max_blocks = 
 // K0: NCHW fp32 -> NHWC4 T
 template <typename T>
 __global__ void k_input_transform(int N, int H, int W, const float* __restrict__ x, T* __restrict__ x4) {
-  const size_t HW = (size_t)H * W, total = (size_t)N * HW;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t n = i / HW, hw = i - n * HW;
-    const float* xp = x + n * 3 * HW + hw;
-    T* o = x4 + i * 4;
-    st1(o + 0, xp[0]);
-    st1(o + 1, xp[HW]);
-    st1(o + 2, xp[2 * HW]);
-    st1(o + 3, 0.f);
+  // grid.y = image; one 8- (16-bit types) or 16-byte store per pixel
+  const size_t HW = (size_t)H * W;
+  const float* xn = x + (size_t)blockIdx.y * 3 * HW;
+  T* on = x4 + (size_t)blockIdx.y * HW * 4;
+  for (size_t hw = blockIdx.x * (size_t)blockDim.x + threadIdx.x; hw < HW; hw += (size_t)gridDim.x * blockDim.x) {
+    const float r = xn[hw], g = xn[HW + hw], b = xn[2 * HW + hw];
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<f32x4_t*>(on + hw * 4) = f32x4_t{r, g, b, 0.f};
+    } else {
+      float f[8] = {r, g, b, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const u32x4_t pk = Vec16<T>::pack(f);
+      *reinterpret_cast<u32x2_t*>(on + hw * 4) = u32x2_t{pk[0], pk[1]};
+    }
   }
 }
 
@@ -83,14 +87,12 @@ __global__ void k_bn_relu_maxpool(int N, int H, int W, int C, const T* __restric
                                   const float* __restrict__ shift, T* __restrict__ pooled, uint8_t* __restrict__ argmax) {
   constexpr int VE = ElemTraits<T>::kVec;
   const int Hp = H / 2, Wp = W / 2, CV = C / VE;
-  const size_t total = (size_t)N * Hp * Wp * CV;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % CV);
-    size_t t = i / CV;
-    const int pw = (int)(t % Wp);
-    t /= Wp;
-    const int ph = (int)(t % Hp);
-    const int n = (int)(t / Hp);
+  // grid = (pooled row segment, pooled row, image): no 64-bit division per element (it was most of this kernel's instructions)
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (unsigned)(Wp * CV)) {
+    const int pw = (int)(t / (unsigned)CV), cv = (int)(t - (unsigned)pw * CV);
+    const int ph = blockIdx.y, n = blockIdx.z;
+    const size_t i = (((size_t)n * Hp + ph) * Wp + pw) * CV + cv;
     float sc[VE], sh[VE], best[VE];
     int bi[VE];
 #pragma unroll
@@ -136,14 +138,12 @@ __global__ void k_maxpool_bwd(int N, int H, int W, int C, const T* __restrict__ 
                               T* __restrict__ dy) {
   constexpr int VE = ElemTraits<T>::kVec;
   const int Hp = H / 2, Wp = W / 2, CV = C / VE;
-  const size_t total = (size_t)N * H * W * CV;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % CV);
-    size_t t = i / CV;
-    const int w = (int)(t % W);
-    t /= W;
-    const int h = (int)(t % H);
-    const int n = (int)(t / H);
+  // grid = (row segment, row, image): no 64-bit division per element
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (unsigned)(W * CV)) {
+    const int w = (int)(t / (unsigned)CV), cv = (int)(t - (unsigned)w * CV);
+    const int h = blockIdx.y, n = blockIdx.z;
+    const size_t i = (((size_t)n * H + h) * W + w) * CV + cv;
     float acc[VE];
 #pragma unroll
     for (int j = 0; j < VE; ++j) acc[j] = 0.f;
@@ -880,7 +880,8 @@ extern "C" int vk_input_transform(vk_dtype dtype, int N, int H, int W, const flo
   VK_CHECK_ARG(x && x4 && N > 0 && H > 0 && W > 0, "vk_input_transform: bad argument");
   hipStream_t st = (hipStream_t)stream;
   vkh::ProfScope ps_("input_transform", st, 0.0, (double)N * H * W * (12.0 + 4.0 * (dtype == VK_F32 ? 4.0 : 2.0)));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(k_input_transform<T>, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, st, N, H, W, x, (T*)x4));
+  VK_CHECK_ARG(N <= 65535, "vk_input_transform: N too large for the launch grid");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_input_transform<T>, dim3(grid_for((size_t)H * W, 256, 1024), (unsigned)N), dim3(256), 0, st, N, H, W, x, (T*)x4));
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }
@@ -903,7 +904,8 @@ extern "C" int vk_bn_relu_maxpool(vk_dtype dtype, int N, int H, int W, int C, co
   VK_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "vk_bn_relu_maxpool: H, W even and C %% 8 == 0 required");
   hipStream_t st = (hipStream_t)stream;
   vkh::ProfScope ps_("bn_relu_maxpool", st, 0.0, (double)N * H * W * C * (dtype == VK_F32 ? 4.0 : 2.0) * 1.25 + (double)N * H * W * C / 4.0);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_relu_maxpool<T>, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * (C / ElemTraits<T>::kVec))),
+  VK_CHECK_ARG(N <= 65535 && H / 2 <= 65535, "vk_bn_relu_maxpool: N or H too large for the launch grid");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_relu_maxpool<T>, dim3((unsigned)(((W / 2) * (C / ElemTraits<T>::kVec) + 255) / 256), (unsigned)(H / 2), (unsigned)N),
                                        dim3(256), 0, st, N, H, W, C, (const T*)z, scale, shift, (T*)pooled, argmax));
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
@@ -914,7 +916,8 @@ extern "C" int vk_maxpool_bwd(vk_dtype dtype, int N, int H, int W, int C, const 
   VK_CHECK_ARG(dpool && argmax && dy && C % 8 == 0, "vk_maxpool_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   vkh::ProfScope ps_("maxpool_bwd", st, 0.0, (double)N * H * W * C * (dtype == VK_F32 ? 4.0 : 2.0) * 2.25 + (double)N * H * W * C / 4.0);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3(grid_for((size_t)N * H * W * (C / ElemTraits<T>::kVec))), dim3(256), 0, st,
+  VK_CHECK_ARG(N <= 65535 && H <= 65535 && H % 2 == 0 && W % 2 == 0, "vk_maxpool_bwd: N or H too large for the launch grid, or odd size");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3((unsigned)((W * (C / ElemTraits<T>::kVec) + 255) / 256), (unsigned)H, (unsigned)N), dim3(256), 0, st,
                                        N, H, W, C, (const T*)dpool, argmax, (T*)dy));
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
