@@ -76,9 +76,14 @@ def main():
             return pk, lib.vk_conv_fwd_packed
         wf, fn_f = weights(d_f, w, K, Ctot)
         wd_, fn_d = weights(d_d, wt, Ctot, K)
+        zprev = torch.randn(N, H, H, Ctot, device=dev).to(dt)          # raw conv output the data gradient is masked by
+        bsc, bsh = torch.rand(Ctot, device=dev) + 0.5, torch.randn(Ctot, device=dev) * 0.1
+        bsums = torch.zeros(32 * 2 * Ctot, dtype=torch.float64, device=dev)
+        bnr = L_.vk_bnr(zprev.data_ptr(), bsc.data_ptr(), bsh.data_ptr(), bsums.data_ptr())
         ops = {
             "fwd": lambda: fn_f(C.byref(d_f), wf.data_ptr(), y.data_ptr(), None, 0, 0, None if a.no_stats else stats.data_ptr(), st),
             "dgrad": lambda: fn_d(C.byref(d_d), wd_.data_ptr(), dx.data_ptr(), None, 0, 0, None, st),
+            "dgrad_bnr": lambda: lib.vk_conv_dgrad_fused(C.byref(d_d), wd_.data_ptr(), dx.data_ptr(), None, 0, 0, C.byref(bnr), st),
             "wgrad": lambda: lib.vk_conv_wgrad(C.byref(d_f), dz.data_ptr(), dw.data_ptr(), wsl.data_ptr(), wsl.numel(), st),
         }
         for op in a.ops.split(","):

@@ -93,7 +93,7 @@ __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 //   * optional channel split (concat gradient): channels >= split go to y1
 //   * optional pool2: the FIRST output part is summed over 2x2 pixel groups and written at half resolution
 //     (nearest-x2 upsample backward fused into the data gradient; the full-resolution tensor never exists)
-template <typename T, int TH, int BN, int TP, int TC, int NT = 256>
+template <typename T, int TH, int BN, int TP, int TC, int NT = 256, bool PRE = false>
 __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP], const HaloParams& p, int n, int y0, int x0, int n0,
                                               int wrow0, int wch0) {
   using Tr = ElemTraits<T>;
@@ -139,11 +139,13 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
     for (int j = 0; j < VE; ++j) { bsc[j] = p.bnr_scale[colx + j]; bsh[j] = p.bnr_shift[colx + j]; }
   }
   // final value of one output vector: optional accumulate, optional BN+ReLU-backward masking + sums, store
-  auto finish = [&](float (&f)[VE], size_t elem_off) {
+  // pre_old / pre_z: the destination's previous content (accumulate) and the matching vector of bnr_z when the caller has
+  // requested them ahead (PRE below); otherwise they are loaded here
+  auto finish = [&](float (&f)[VE], size_t elem_off, const u32x4_t* pre_old, const u32x4_t* pre_z) {
     u32x4_t* gp = reinterpret_cast<u32x4_t*>(yb + elem_off * EB);
     if (p.accumulate) {
       float o[VE];
-      Vec16<T>::unpack(*gp, o);
+      Vec16<T>::unpack(pre_old ? *pre_old : *gp, o);
 #pragma unroll
       for (int j = 0; j < VE; ++j) f[j] += o[j];
     }
@@ -151,7 +153,7 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
     Vec16<T>::unpack(v, f);                      // statistics are over the STORED (rounded) values
     if (bnr) {
       float zf[VE];
-      Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>((const char*)p.bnr_z + elem_off * EB), zf);
+      Vec16<T>::unpack(pre_z ? *pre_z : *reinterpret_cast<const u32x4_t*>((const char*)p.bnr_z + elem_off * EB), zf);
 #pragma unroll
       for (int j = 0; j < VE; ++j) {
         if (!(fmaf(zf[j], bsc[j], bsh[j]) > 0.f)) f[j] = 0.f;
@@ -183,10 +185,28 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
 #pragma unroll
           for (int j = 0; j < VE; ++j) f[j] += t[j];
         }
-        finish(f, (((size_t)n * Hh + y) * Wh + x) * ld + colx);
+        finish(f, (((size_t)n * Hh + y) * Wh + x) * ld + colx, nullptr, nullptr);
       }
     }
   } else {
+    // PRE: request the accumulate / bnr operands of all EPASS vectors before the first one is finished (one memory round
+    // trip instead of EPASS; pays on the 64-channel tiles with 8 passes per thread: L1 data gradient + reduce 73 -> 70 us,
+    // costs registers, hence occupancy, on the C = 16 kernels: off there)
+    u32x4_t oldv[PRE ? EPASS : 1], zv[PRE ? EPASS : 1];
+    if (PRE && (p.accumulate || bnr)) {
+#pragma unroll
+      for (int ps = 0; ps < (PRE ? EPASS : 0); ++ps) {
+        const int row = e_row + ps * ERPP;
+        const int y = y0 + (row >> 4), x = x0 + (row & 15);
+        oldv[ps] = u32x4_t{0, 0, 0, 0};
+        zv[ps] = u32x4_t{0, 0, 0, 0};
+        if (y < p.H && x < p.W && col_ok) {
+          const size_t eoff = (((size_t)n * p.H + y) * p.W + x) * ld + colx;
+          if (p.accumulate) oldv[ps] = *reinterpret_cast<const u32x4_t*>(yb + eoff * EB);
+          if (bnr) zv[ps] = *reinterpret_cast<const u32x4_t*>((const char*)p.bnr_z + eoff * EB);
+        }
+      }
+    }
 #pragma unroll
     for (int ps = 0; ps < EPASS; ++ps) {
       const int row = e_row + ps * ERPP;          // tile pixel index
@@ -197,7 +217,8 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
         float f[VE];
         if (p.accumulate || bnr) {
           Vec16<T>::unpack(raw, f);
-          finish(f, eoff);
+          if (PRE) finish(f, eoff, &oldv[ps], &zv[ps]);
+          else finish(f, eoff, nullptr, nullptr);
         } else {
           // plain store: the LDS tile already holds the rounded values, so they go out as they are (no pack / unpack round
           // trip) and only a launch that wants BN statistics pays for the sums
@@ -712,7 +733,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
   unsigned long long te0, te1;
   VK_T(te0)
 #endif
-  halo_epilogue<T, TH, BN, TP, TC, NT>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
+  halo_epilogue<T, TH, BN, TP, TC, NT, (BN <= 64 && TH == 16)>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
 #ifdef VK_STAMP
   VK_T(te1)
   if (p.stamps && lane == 0) {
