@@ -13,6 +13,7 @@
  *   vk_amp_check_inf .......................... GradScaler inf check          train.py:443-445 (610-611)
  *   vk_conv_fwd / vk_conv_wgrad / ... ......... the ATen operators the reference dispatches to
  *                                               (conv2d, batch_norm, relu, max_pool2d, interpolate, cat)
+ *   vk_conv_fwd_splitk ........................ the same convolutions at batch 1 (predict_mask / Segmenter.infer)
  *   vk_letterbox_preprocess ................... letterbox + BGR->RGB + normalise   infer_pth_gui.py:17-24, 46-49;
  *                                               ui_infer_quadrilateral.py:197-216, 662-678; ui_infer_rectangle.py:225-245, 520-535
  *   vk_letterbox_postprocess_mask ............. sigmoid, threshold, un-letterbox  infer_pth_gui.py:26-29, 50-53
@@ -115,6 +116,14 @@ int vk_halo_pack(vk_dtype dtype, int rows, int red, const void* src, void* dst, 
 int vk_conv_uses_halo_pack(const vk_conv_desc* d);
 int vk_conv_fwd_packed(const vk_conv_desc* d, const void* w_halo, void* y, void* y1, int split_k1, int accumulate, double* stats,
                        void* stream);
+
+/* vk_conv_fwd_packed without statistics for SMALL grids (batch-1 inference, predict_mask / Segmenter.infer:
+ * infer_pth_gui.py:51, ui_infer_quadrilateral.py:705-707): when the layer has fewer than 128 output tiles the channel
+ * reduction is cut into up to 32 slices that run as separate workgroups, write fp32 partial tiles into `workspace`
+ * ([slices][N*H*W][K] floats; fewer slices when it is smaller, none when NULL) and are added up in slice order by a second
+ * launch — same result on every run.  Larger grids run exactly as vk_conv_fwd_packed. */
+#define VK_SPLITK_WORKSPACE_BYTES (32u << 20)
+int vk_conv_fwd_splitk(const vk_conv_desc* d, const void* w_halo, void* y, void* workspace, size_t workspace_bytes, void* stream);
 
 /* BatchNorm+ReLU backward reduce fused into the kernel that produces the gradient: with y the gradient w.r.t. the
  * activated tensor relu(z*scale+shift), the kernel stores g = y * [z*scale+shift > 0] instead of y and adds sum(g),

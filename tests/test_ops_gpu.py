@@ -167,6 +167,65 @@ def test_conv_fwd(case, dtn, conv_path):
     assert torch.allclose(s[K:], (yy * yy).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
 
 
+SPLITK_CASES = [
+    # name, N, H, C_up, C_skip, K   (C_up == 0: plain source with the BN+ReLU prologue)
+    ("l3_n1", 1, 32, 0, 256, 256),
+    ("l4_n1", 1, 16, 0, 512, 512),
+    ("l2_ragged", 1, 27, 0, 128, 128),
+    ("dec0_concat", 1, 32, 512, 256, 256),
+    ("l1_k64", 1, 24, 0, 64, 64),
+]
+
+
+@pytest.mark.parametrize("force", [None, "2", "5", "32"], ids=["auto", "ks2", "ks5", "ks32"])
+@pytest.mark.parametrize("dtn", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=[c[0] for c in SPLITK_CASES])
+def test_conv_fwd_splitk(case, dtn, force, monkeypatch):
+    """vk_conv_fwd_splitk (batch-1 inference): slices of the channel chunks in separate workgroups + ordered reduce, against
+    conv2d; the result must not depend on the run (two launches compared bit for bit)."""
+    dt = DT[dtn]
+    _, N, H, Cup, Cc, K = case
+    if force is None:
+        monkeypatch.delenv("VK_SPLITK", raising=False)
+    else:
+        monkeypatch.setenv("VK_SPLITK", force)
+    x = gen(N, Cc, H, H, seed=11)
+    sc_c = 0.5 + torch.rand(Cc, generator=torch.Generator().manual_seed(12))
+    sh_c = gen(Cc, seed=13, scale=0.3)
+    v = rnd(torch.relu(rnd(x, dt) * sc_c.view(1, -1, 1, 1) + sh_c.view(1, -1, 1, 1)), dt)
+    xd, scd, shd = to_nhwc(x, dt), D(sc_c), D(sh_c)
+    s0, s1 = mk_src(xd, Cc, 0, scd, shd, 1), null_src()
+    if Cup:
+        lo = gen(N, Cup, H // 2, H // 2, seed=14)
+        lod = to_nhwc(lo, dt)
+        v = torch.cat([F.interpolate(rnd(lo, dt), scale_factor=2, mode="nearest"), v], dim=1)
+        s0, s1 = mk_src(lod, Cup, 1), s0
+    Ct = Cup + Cc
+    w = gen(K, Ct, 3, 3, seed=15, scale=(2.0 / (Ct * 9)) ** 0.5)
+    wd = D(w.permute(0, 2, 3, 1).contiguous().to(dt))
+    ref = F.conv2d(v.double(), rnd(w, dt).double(), padding=1).float()
+    d = conv_desc(dt, N, H, H, H, H, K, 3, 1, 1, 0, s0, s1)
+    wp, packed = conv_w(d, wd)
+    assert packed
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev())
+    outs = []
+    for _ in range(2):
+        y = torch.full((N, H, H, K), float("nan"), dtype=dt, device=dev())
+        L_.check(vk.lib().vk_conv_fwd_splitk(C.byref(d), wp.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), st()))
+        torch.cuda.synchronize()
+        outs.append(y)
+    got = from_nhwc(outs[0])
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= tol(dt, ref), f"max err {err} vs tol {tol(dt, ref)}"
+    assert torch.equal(outs[0], outs[1])
+    # no workspace: runs unsplit, same numbers up to the summation order
+    y2 = torch.empty_like(outs[0])
+    L_.check(vk.lib().vk_conv_fwd_splitk(C.byref(d), wp.data_ptr(), y2.data_ptr(), None, 0, st()))
+    torch.cuda.synchronize()
+    assert (from_nhwc(y2) - ref).abs().max().item() <= tol(dt, ref)
+
+
 @pytest.mark.parametrize("dtn", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape", [(2, 16, 64, 32, 32), (1, 8, 512, 256, 256), (1, 32, 32, 0, 16)],
                          ids=["d3", "d0", "d4_noskip"])

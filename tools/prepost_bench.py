@@ -99,6 +99,18 @@ def main():
     print(json.dumps(dict(case="16 x 1200x1600 BGR (resident) -> probability maps, fp32 forward", total_ms=round(t_all / 1e3, 3),
                           forward_only_ms=round(t_fwd / 1e3, 3), pre_post_share=round(1 - t_fwd / t_all, 4),
                           images_per_s=round(16 / (t_all / 1e6), 1))), flush=True)
+    # the GUI's own unit of work: ONE pageable host image -> probability map on the host (upload, pre, forward bs 1, post, download)
+    host_img = rng.integers(0, 256, (1200, 1600, 3), dtype=np.uint8)
+    for dt_name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        model.compute_dtype = dt
+        for _ in range(3):
+            seg.infer(host_img)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            seg.infer(host_img)
+        t1 = (time.perf_counter() - t0) / 20 * 1e3
+        print(json.dumps(dict(case=f"Segmenter.infer, one 1200x1600 host image, {dt_name} forward, host to host", ms=round(t1, 3))), flush=True)
 
 
 if __name__ == "__main__":

@@ -67,6 +67,7 @@ SIGNATURES = {
     "vk_halo_pack": (ci, [ci, ci, ci, vp, vp, vp]),
     "vk_conv_uses_halo_pack": (ci, [P(vk_conv_desc)]),
     "vk_conv_fwd_packed": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp, vp]),
+    "vk_conv_fwd_splitk": (ci, [P(vk_conv_desc), vp, vp, vp, sz, vp]),
     "vk_stem_fwd": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     "vk_conv_wgrad": (ci, [P(vk_conv_desc), vp, vp, vp, sz, vp]),
     "vk_stem_wgrad": (ci, [ci, ci, ci, ci, vp, vp, vp, vp]),

@@ -48,6 +48,9 @@ struct HaloParams {
   // fused BatchNorm+ReLU backward reduce on the first output part: g = y * [z*scale+shift > 0] is stored instead of y and
   // sum(g), sum(g*z) go to bnr_sums [VK_STATS_REPLICAS][2][ld0]
   unsigned long long* stamps;   // diagnostic builds (-DVK_STAMP) only
+  int ksplit;                   // > 1: blockIdx.z owns a slice of the channel chunks and writes an fp32 partial tile into `slab`
+  size_t slab_bytes;
+  float* slab;                  //      [ksplit][N*H*W][K]; k_splitk_reduce adds the slices up in a fixed order (small grids: batch-1 inference)
   int dbg;                      // timing experiments (VK_COL_DBG, results are WRONG by construction): 1 = weight descriptor with zero
                                 // records, 2 = no LDS-DMA in the loop, 4 = no halo refresh in the loop, 8 = no stage barriers
   const void* bnr_z;
@@ -686,18 +689,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
   unsigned long long t_begin, t_pro, tk_load = 0, tk_comp = 0, tk_store = 0, tk_bar = 0;
   VK_T(t_begin)
 #endif
-  // ---- prologue: chunk 0 halo + stage 0 weights
-  load_halo(0);
-  dma_b(0, 0, 0);
+  // ---- prologue: first chunk's halo + stage 0 weights (split-K: this workgroup's slice of the chunks)
+  const int ksp = p.ksplit > 1 ? p.ksplit : 1;
+  const int c_begin = (int)((long)p.nchunks * blockIdx.z / ksp), c_end = (int)((long)p.nchunks * (blockIdx.z + 1) / ksp);
+  load_halo(c_begin);
+  dma_b(c_begin, 0, 0);
   store_halo(Abuf);
   __syncthreads();                                        // also drains the LDS-DMA (vmcnt(0))
   VK_T(t_pro)
 
   int st = 0;
-  for (int cc = 0; cc < p.nchunks; ++cc) {
-    const bool next_chunk = cc + 1 < p.nchunks;
-    const char* A = Abuf + (ADB ? (cc & 1) * Cfg::A_BYTES : 0) + a_lane;
-    char* const Anext = Abuf + (ADB ? ((cc + 1) & 1) * Cfg::A_BYTES : 0);
+  for (int cc = c_begin; cc < c_end; ++cc) {
+    const bool next_chunk = cc + 1 < c_end;
+    const char* A = Abuf + (ADB ? ((cc - c_begin) & 1) * Cfg::A_BYTES : 0) + a_lane;
+    char* const Anext = Abuf + (ADB ? ((cc - c_begin + 1) & 1) * Cfg::A_BYTES : 0);
 #pragma unroll
     for (int s = 0; s < 3; ++s, ++st) {
 #ifdef VK_STAMP
@@ -733,6 +738,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
   unsigned long long te0, te1;
   VK_T(te0)
 #endif
+  if (p.ksplit > 1) {
+    // partial tile straight from the accumulators: lane = pixel li, four consecutive channels per 16-byte store
+    float* sl = p.slab + (size_t)blockIdx.z * ((size_t)p.N * p.H * p.W * p.K);
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) {
+        const int y = y0 + wrow0 + b, x = x0 + li, ch = n0 + wch0 + a * 16 + kg * 4;
+        if (y < p.H && x < p.W && ch < p.K) *reinterpret_cast<f32x4_t*>(sl + (((size_t)n * p.H + y) * p.W + x) * p.K + ch) = acc[a][b];
+      }
+    return;
+  }
   halo_epilogue<T, TH, BN, TP, TC, NT, (BN <= 64 && TH == 16)>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
 #ifdef VK_STAMP
   VK_T(te1)
@@ -934,12 +951,44 @@ static int launch_halo(HaloParams p, hipStream_t st) {
   return VK_OK;
 }
 
+// y[e] = T(sum_s slab[s][e]) in slice order (reproducible), four elements per thread
+template <typename T>
+__global__ __launch_bounds__(256) void k_splitk_reduce(size_t n4, int splits, const float* __restrict__ slab, T* __restrict__ y) {
+  const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (e >= n4) return;
+  f32x4_t a = *reinterpret_cast<const f32x4_t*>(slab + e * 4);
+  for (int s = 1; s < splits; ++s) a = a + *reinterpret_cast<const f32x4_t*>(slab + ((size_t)s * n4 + e) * 4);
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<f32x4_t*>(y + e * 4) = a;
+  } else {
+    float f[8] = {a[0], a[1], a[2], a[3], 0.f, 0.f, 0.f, 0.f};
+    const u32x4_t pk = Vec16<T>::pack(f);
+    *reinterpret_cast<u32x2_t*>(y + e * 4) = u32x2_t{pk[0], pk[1]};
+  }
+}
+
 template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW>
 static int launch_col(HaloParams p, hipStream_t st) {
   using Cfg = ColCfg<T, TH, BN, WGM, WGN, ADB>;
   p.tiles_x = (p.W + 15) / 16;
   p.tiles_y = (p.H + TH - 1) / TH;
   dim3 grid((unsigned)(p.N * p.tiles_y * p.tiles_x), (unsigned)((p.K + BN - 1) / BN), 1);
+  // split-K for grids that leave most of the chip idle (batch-1 inference: 8-64 tiles per layer): slices of the channel
+  // chunks in blockIdx.z, fp32 partial tiles into the caller's workspace, one reduce launch.  Only the plain path (no
+  // statistics / accumulate / fused gradients), so training launches never take it.
+  const size_t out_elems = (size_t)p.N * p.H * p.W * p.K;
+  int ks = 1;
+  if (p.slab && !p.stats && !p.bnr_z && !p.accumulate && !p.pool2 && p.split == 0 && !getenv("VK_NO_SPLITK")) {
+    const long wgs = (long)grid.x * grid.y;
+    const char* force = getenv("VK_SPLITK");
+    ks = force ? atoi(force) : (wgs < 128 ? (int)(256 / wgs) : 1);
+    if (ks > p.nchunks / 2) ks = p.nchunks / 2;             // at least two chunks (six pipeline stages) per slice
+    if (ks > 32) ks = 32;
+    while (ks > 1 && (size_t)ks * out_elems * sizeof(float) > p.slab_bytes) --ks;
+    if (ks < 2) ks = 1;
+  }
+  p.ksplit = ks;
+  grid.z = (unsigned)ks;
   static bool attr_done = false;
   if (!attr_done && Cfg::SMEM > 64 * 1024) {
     VK_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_col_kernel<T, TH, BN, WGM, WGN, ADB, MINW>,
@@ -956,6 +1005,10 @@ static int launch_col(HaloParams p, hipStream_t st) {
     const std::string dtag = getenv("VK_PROF_DETAIL") ? btag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) : btag;
     vkh::ProfScope ps(dtag.c_str(), st, 2.0 * macs, bytes);
     hipLaunchKernelGGL((conv3x3_col_kernel<T, TH, BN, WGM, WGN, ADB, MINW>), grid, dim3(Cfg::NT), Cfg::SMEM, st, p);
+  }
+  if (ks > 1) {
+    vkh::ProfScope ps("splitk_reduce", st, 0.0, (double)out_elems * (4.0 * ks + sizeof(T)));
+    hipLaunchKernelGGL(k_splitk_reduce<T>, dim3((unsigned)((out_elems / 4 + 255) / 256)), dim3(256), 0, st, out_elems / 4, ks, p.slab, (T*)p.y0);
   }
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
@@ -1024,7 +1077,7 @@ static int launch_c16(HaloParams p, hipStream_t st) {
 // returns VK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the tap-by-tap kernel)
 // w: halo pack (vk_halo_pack) when `packed`, plain [K][3][3][C] otherwise — only the C == 16 kernel takes the plain layout
 int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, void* y1, int split_k1, int accumulate, double* stats,
-                     int pool2, const vk_bnr* bnr, hipStream_t st) {
+                     int pool2, const vk_bnr* bnr, hipStream_t st, void* workspace, size_t workspace_bytes) {
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->H != d->Ho || d->W != d->Wo) return VK_ERR_UNSUPPORTED;
   const int eb = d->dtype == VK_F32 ? 4 : 2;
   const int ck = 64 / eb;
@@ -1056,6 +1109,9 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, 
   p.flip = d->transposed;
   p.accumulate = accumulate;
   p.pool2 = pool2;
+  p.ksplit = 1;
+  p.slab = (float*)workspace;
+  p.slab_bytes = workspace_bytes;
   p.stamps = nullptr;
   p.dbg = getenv("VK_COL_DBG") ? atoi(getenv("VK_COL_DBG")) : 0;
   if (p.dbg & 1) p.w_bytes = 0;

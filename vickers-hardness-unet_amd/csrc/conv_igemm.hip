@@ -520,7 +520,7 @@ static int dispatch(vk_dtype dt, const ConvParams& p, int mode, hipStream_t st) 
 }
 
 int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, void* y1, int split_k1, int accumulate, double* stats,
-                     int pool2, const vk_bnr* bnr, hipStream_t st);
+                     int pool2, const vk_bnr* bnr, hipStream_t st, void* workspace, size_t workspace_bytes);
 int halo_pack_impl(vk_dtype dt, int rows, int red, const void* src, void* dst, hipStream_t st);
 
 static bool is_c16(const vk_conv_desc* d) {
@@ -533,7 +533,7 @@ static bool halo_enabled() {
 }
 
 int conv_fwd_impl(const vk_conv_desc* d, const void* w, int packed, void* y, void* y1, int split_k1, int accumulate,
-                  double* stats, int pool2, const vk_bnr* bnr, hipStream_t st) {
+                  double* stats, int pool2, const vk_bnr* bnr, hipStream_t st, void* workspace = nullptr, size_t workspace_bytes = 0) {
   VK_CHECK_ARG(d && w && y, "vk_conv_fwd: null argument");
   const int eb = d->dtype == VK_F32 ? 4 : 2;
   const int ve = 16 / eb;
@@ -553,7 +553,7 @@ int conv_fwd_impl(const vk_conv_desc* d, const void* w, int packed, void* y, voi
   VK_CHECK_ARG(!(d->src1.ptr && d->src1.up), "vk_conv_fwd: only src0 may be upsampled");
   if (halo_enabled() && (!d->transposed || d->stride == 1)) {
     // 3x3 stride-1 convolutions (and their data gradients) go to the LDS-staged halo kernel
-    const int rc = conv3x3_halo_try(d, w, packed, y, y1, split_k1, accumulate, stats, pool2, bnr, st);
+    const int rc = conv3x3_halo_try(d, w, packed, y, y1, split_k1, accumulate, stats, pool2, bnr, st, workspace, workspace_bytes);
     if (rc != VK_ERR_UNSUPPORTED) return rc;
   }
   if (packed) {
@@ -657,6 +657,10 @@ extern "C" int vk_conv_dgrad_fused(const vk_conv_desc* d, const void* w, void* y
 extern "C" int vk_conv_fwd_packed(const vk_conv_desc* d, const void* w_halo, void* y, void* y1, int split_k1, int accumulate, double* stats,
                                   void* stream) {
   return vk::conv_fwd_impl(d, w_halo, 1, y, y1, split_k1, accumulate, stats, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int vk_conv_fwd_splitk(const vk_conv_desc* d, const void* w_halo, void* y, void* workspace, size_t workspace_bytes, void* stream) {
+  return vk::conv_fwd_impl(d, w_halo, 1, y, nullptr, 0, 0, nullptr, 0, nullptr, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 extern "C" int vk_halo_pack(vk_dtype dtype, int rows, int red, const void* src, void* dst, void* stream) {

@@ -291,7 +291,7 @@ struct vk_unet {
   size_t ws_bytes = 0;
   size_t off_x4 = 0, off_pool = 0, off_argmax = 0, off_gpool = 0, off_dup = 0, off_dlogits = 0, off_loss_sums = 0;
   size_t off_stats = 0, off_bsums = 0, stats_bytes = 0, off_farena = 0, farena_floats = 0, off_wf = 0, off_wd = 0, off_wstem = 0;
-  size_t off_tab_pack = 0, off_tab_bn = 0, off_wslab = 0, off_wh = 0, off_tab_halo = 0;
+  size_t off_tab_pack = 0, off_tab_bn = 0, off_wslab = 0, off_wh = 0, off_tab_halo = 0, off_splitk = 0, splitk_bytes = 0;
   std::vector<HaloPackEntry> halo_tab;
   std::vector<size_t> off_z, off_g, off_out, off_gout;
   std::vector<char> g_prereduced;      // per conv: its gradient buffer already holds masked g + sums (vk_bnr fusion)
@@ -516,6 +516,9 @@ void layout_workspace(vk_unet* h) {
   h->off_tab_halo = take(2 * h->convs.size() * sizeof(HaloPackEntry));
   h->off_wstem = take(64 * 7 * 32 * eb);
   h->off_wslab = tr ? take(VK_WGRAD_WORKSPACE_BYTES) : 0;
+  // eval plans with few tiles per layer (batch-1 inference) split the channel reduction: scratch for the partial tiles
+  h->splitk_bytes = (!tr && (size_t)N * S * S <= 4u * 512 * 512) ? VK_SPLITK_WORKSPACE_BYTES : 0;
+  h->off_splitk = h->splitk_bytes ? take(h->splitk_bytes) : 0;
   h->off_tab_pack = take(h->convs.size() * sizeof(PackEntry));
   h->off_tab_bn = take(h->bns.size() * sizeof(BnEvalEntry));
   h->ws_bytes = off;
@@ -614,7 +617,8 @@ int finalize_bn(vk_unet* h, BnL& b, int training, hipStream_t st) {
 int run_conv(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, int training, hipStream_t st) {
   vk_conv_desc d = conv_desc(h, c, s0, s1);
   BnL& b = h->bns[c.bn];
-  if (c.halo_fwd) RET_IF(vk_conv_fwd_packed(&d, fwd_weights(h, c), c.z, nullptr, 0, 0, training ? b.stats : nullptr, st));
+  if (c.halo_fwd && !training && h->splitk_bytes) RET_IF(vk_conv_fwd_splitk(&d, fwd_weights(h, c), c.z, h->ws + h->off_splitk, h->splitk_bytes, st));
+  else if (c.halo_fwd) RET_IF(vk_conv_fwd_packed(&d, fwd_weights(h, c), c.z, nullptr, 0, 0, training ? b.stats : nullptr, st));
   else RET_IF(vk_conv_fwd(&d, fwd_weights(h, c), c.z, nullptr, 0, 0, training ? b.stats : nullptr, st));
   return finalize_bn(h, b, training, st);
 }
