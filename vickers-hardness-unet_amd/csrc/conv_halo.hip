@@ -1110,8 +1110,8 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, 
   p.accumulate = accumulate;
   p.pool2 = pool2;
   p.ksplit = 1;
-  p.slab = (float*)workspace;
-  p.slab_bytes = workspace_bytes;
+  p.slab = (reinterpret_cast<uintptr_t>(workspace) & 15) ? nullptr : (float*)workspace;      // 16-byte stores into the slab
+  p.slab_bytes = p.slab ? workspace_bytes : 0;
   p.stamps = nullptr;
   p.dbg = getenv("VK_COL_DBG") ? atoi(getenv("VK_COL_DBG")) : 0;
   if (p.dbg & 1) p.w_bytes = 0;
