@@ -99,9 +99,9 @@ def conv_run(d, w, y, y1=None, split=0, acc=0, stats=None, plain=False):
     return packed
 
 
-@pytest.fixture(params=["tile", "tile_alt1", "tile_alt2", "tile_alt3", "tile_alt7", "tap"])
+@pytest.fixture(params=["tile", "tile_alt1", "tile_alt2", "tile_alt3", "tile_alt7", "tile_alt8", "tap"])
 def conv_path(request, monkeypatch):
-    """tile: 3x3 stride-1 tile kernels with halo-pack weights (alt1/2/3/7: each tile shape of the K >= 128 class forced);
+    """tile: 3x3 stride-1 tile kernels with halo-pack weights (alt1/2/3/7/8: each tile shape of the K >= 128 class forced);
     tap: the tap-by-tap implicit-GEMM kernel with plain weights."""
     if request.param.startswith("tile_alt"):
         monkeypatch.setenv("VK_COL_ALT", request.param[-1])

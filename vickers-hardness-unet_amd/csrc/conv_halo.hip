@@ -1016,7 +1016,7 @@ static int launch_col(HaloParams p, hipStream_t st) {
 
 // tile selection for the column-staged kernels.  VK_COL_ALT (diagnostic / tests) forces a shape of the K >= 128 class:
 //   1: 4 waves, 16x16x128, 8 rows x 64 channels per wave (one wave per SIMD);  2: the 8-wave 16x16x128 tile;  3: the 4-wave 8x16x128 tile;
-//   7: the 8-wave 8x16x128 tile
+//   7: the 8-wave 8x16x128 tile;  8: the 4-wave 16x16x64 tile
 template <typename T>
 static int col_select(const HaloParams& p, hipStream_t st) {
   const char* alt_s = getenv("VK_COL_ALT");
@@ -1025,6 +1025,9 @@ static int col_select(const HaloParams& p, hipStream_t st) {
   if (p.K >= 128) {
     const long kt = (p.K + 127) / 128;
     if (alt == 1) return launch_col<T, 16, 128, 2, 2, true, 1>(p, st);
+    // a short reduction onto a channel count that is not a multiple of 128 (the concat gradient of decoder block 2: 64 -> 192):
+    // 64-channel tiles waste no half-empty channel tile (201 -> 156 us stand-alone)
+    if (alt == 8 || (alt == 0 && p.nchunks <= 2 && p.K % 128 != 0)) return launch_col<T, 16, 64, 4, 1, false, 2>(p, st);
     // a reduction of one or two channel chunks (the concat gradients of decoder blocks 2/3: HBM / epilogue-bound, thousands of
     // tiles): the 4-wave 8x16x128 tile, two workgroups per CU
     if (alt == 3 || (alt != 2 && alt != 7 && p.nchunks <= 2)) return launch_col<T, 8, 128, 2, 2, false, 2>(p, st);
