@@ -124,6 +124,15 @@ def test_c_abi_argument_errors(vk):
     assert L.vk_unet_tensor_info(h, 10_000, C.byref(ti)) < 0
     L.vk_unet_destroy(h)
     assert L.vk_adamw_step(0, None, None, None, None, 0.0, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None, None, 0, None) < 0
+    # pre/post-processing descriptors are checked on the host before anything is launched
+    lb = vk._lib.vk_letterbox_desc
+    assert L.vk_letterbox_preprocess(None, None, None, None) < 0
+    assert L.vk_letterbox_preprocess(C.byref(lb(10, 10, 30, 64, 70, 10, 0, 0, 0)), None, None, None) < 0      # 70 rows in a 64 square
+    assert b"does not fit" in L.vk_last_error_string()
+    assert L.vk_letterbox_preprocess(C.byref(lb(10, 10, 30, 64, 10, 10, 0, 0, 300)), None, None, None) < 0     # border value > 255
+    assert L.vk_letterbox_postprocess_mask(C.byref(lb(10, 10, 0, 64, 10, 10, 60, 0, 0)), None, 0.5, None, None) < 0   # top + nh > S
+    assert L.vk_letterbox_postprocess_prob(C.byref(lb(10, 10, 0, 64, 10, 10, 0, 0, 0)), None, None, None) < 0  # null buffers
+    assert L.vk_conv_fwd_splitk(None, None, None, None, 0, None) < 0
 
 
 def test_optimizer_is_a_torch_optimizer(vk):
