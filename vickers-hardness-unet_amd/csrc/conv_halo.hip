@@ -297,6 +297,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
 
   // block -> (image, tile y, tile x), channel tile
   int bt = blockIdx.x;
+  // workgroups go round-robin over the 8 XCDs: give every XCD (its own L2) a contiguous run of tiles so that horizontally
+  // adjacent tiles share their halo columns in one L2 (kernel level +1-2 % on the HBM-bound layers, null on the step)
+  if ((gridDim.x & 7) == 0) bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);
   const int tx = bt % p.tiles_x;
   bt /= p.tiles_x;
   const int ty = bt % p.tiles_y;
@@ -558,6 +561,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   int bt = blockIdx.x;
+  // workgroups go round-robin over the 8 XCDs: give every XCD (its own L2) a contiguous run of tiles so that horizontally
+  // adjacent tiles share their halo columns in one L2 (kernel level +1-2 % on the HBM-bound layers, null on the step)
+  if ((gridDim.x & 7) == 0) bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);
   const int tx = bt % p.tiles_x;
   bt /= p.tiles_x;
   const int ty = bt % p.tiles_y;
@@ -788,6 +794,9 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const HaloParams p) {
   char* const Bbuf = smem + Cfg::A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bt = blockIdx.x;
+  // workgroups go round-robin over the 8 XCDs: give every XCD (its own L2) a contiguous run of tiles so that horizontally
+  // adjacent tiles share their halo columns in one L2 (kernel level +1-2 % on the HBM-bound layers, null on the step)
+  if ((gridDim.x & 7) == 0) bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);
   const int tx = bt % p.tiles_x;
   bt /= p.tiles_x;
   const int ty = bt % p.tiles_y;
