@@ -54,14 +54,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal of the multi-rank control flow on a ONE-GPU box: VK_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
+    # (RCCL refuses two ranks on one device).  Never set for a measurement.
+    rehearsal = bool(os.environ.get("VK_BENCH_REHEARSAL"))
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
     force_dist = bool(os.environ.get("VK_BENCH_FORCE_DIST"))      # exercise the RCCL path with a single rank (testing)
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     vk = importlib.import_module("vickers-hardness-unet_amd")
     from oracle import unet_oracle as O      # synthetic data generator + (rank 0) CPU baseline only
@@ -96,7 +103,7 @@ def main():
 
     def barrier():
         if world > 1 or force_dist:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
 
     for i in range(args.warmup):
         out = step()
@@ -124,12 +131,15 @@ def main():
     # ---- per-kernel-family timing with HIP events on the launch stream (a few extra, untimed-for-value steps)
     roof = None
     table = {}
+    # EVERY rank runs these steps (they contain the gradient all-reduces: rank 0 alone would wait for its peers for ever);
+    # only rank 0 brackets its launches with events and reports
+    L = vk.lib()
     if rank == 0:
-        L = vk.lib()
         L.vk_prof_enable(1)
-        for _ in range(args.prof_steps):
-            step()
-        torch.cuda.synchronize()
+    for _ in range(args.prof_steps):
+        step()
+    torch.cuda.synchronize()
+    if rank == 0:
         L.vk_prof_enable(0)
         table = vk._lib.prof_collect()
         _log("event profile collected")
