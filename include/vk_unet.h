@@ -191,6 +191,11 @@ int vk_bn_relu_maxpool(vk_dtype dtype, int N, int H, int W, int C, const void* z
 /* dy[N][H][W][C] += scatter(dpool) through argmax */
 int vk_maxpool_bwd(vk_dtype dtype, int N, int H, int W, int C, const void* dpool, const uint8_t* argmax, void* dy,
                    void* stream);
+/* vk_maxpool_bwd and the BatchNorm+ReLU-backward reduce of the tensor under the pool in one pass (stem tail): dy holds the other
+ * gradient contributions on entry and g = (dy + maxpool backward) * [relu(z*scale+shift) > 0] on return; sum(g), sum(g*z) are added
+ * into sums [VK_STATS_REPLICAS][2][C].  Phase 2 is vk_bn_bwd_apply with mask_mode 0. */
+int vk_maxpool_bwd_bn_reduce(vk_dtype dtype, int N, int H, int W, int C, const void* dpool, const uint8_t* argmax, const void* z,
+                             const float* scale, const float* shift, void* dy, double* sums, void* stream);
 
 /* out = relu(z*scale+shift + (res*rscale+rshift | res)) — BasicBlock tail */
 int vk_bn_add_relu(vk_dtype dtype, size_t pixels, int C, const void* z, const float* scale, const float* shift,

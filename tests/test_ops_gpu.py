@@ -578,6 +578,22 @@ def test_bn_relu_maxpool_and_bwd(dtn):
     vk._lib.check(vk.lib().vk_maxpool_bwd(L_.dtype_code(dt), N, H, H, Cc, to_nhwc(dp, dt).data_ptr(), am.data_ptr(), dy.data_ptr(), st()))
     torch.cuda.synchronize()
     assert (from_nhwc(dy) - want).abs().max().item() <= tol(dt, want) * 2
+    # fused form (stem tail): the same gather + the BN+ReLU-backward mask and sums in one pass; dy2 ends as g = dy * mask
+    dy2 = to_nhwc(base, dt)
+    sums = torch.zeros(REPL * 2 * Cc, dtype=torch.float64, device=dev())
+    vk._lib.check(vk.lib().vk_maxpool_bwd_bn_reduce(L_.dtype_code(dt), N, H, H, Cc, to_nhwc(dp, dt).data_ptr(), am.data_ptr(), zd.data_ptr(),
+                                                    D(sc_c).data_ptr(), D(sh_c).data_ptr(), dy2.data_ptr(), sums.data_ptr(), st()))
+    torch.cuda.synchronize()
+    # the kernel masks with fmaf(z, scale, shift) > 0: the sign of the exactly rounded value (double arithmetic here)
+    mask = ((from_nhwc(zd).double() * sc_c.double().view(1, -1, 1, 1) + sh_c.double().view(1, -1, 1, 1)) > 0).float()
+    g_want = from_nhwc(dy) * mask                  # the unfused kernels' result, masked
+    got = from_nhwc(dy2)
+    assert torch.equal(got, g_want), f"max diff {(got - g_want).abs().max().item()}"
+    sm = sums.cpu().view(REPL, 2 * Cc).sum(0)
+    zz = from_nhwc(zd).double()
+    gd = got.double()
+    assert torch.allclose(sm[:Cc], gd.sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(sm[Cc:], (gd * zz).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])

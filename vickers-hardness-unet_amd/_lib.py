@@ -78,6 +78,7 @@ SIGNATURES = {
     "vk_bn_finalize": (ci, [ci, ci, vp, cd, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
     "vk_bn_relu_maxpool": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
     "vk_maxpool_bwd": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp]),
+    "vk_maxpool_bwd_bn_reduce": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     "vk_bn_add_relu": (ci, [ci, sz, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     "vk_bn_bwd_reduce": (ci, [ci, sz, ci, vp, vp, ci, vp, vp, vp, vp, vp]),
     "vk_bn_bwd_coeffs": (ci, [ci, vp, cd, vp, vp, vp, vp, vp, vp, vp]),

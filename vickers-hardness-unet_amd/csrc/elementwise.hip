@@ -245,6 +245,108 @@ __global__ __launch_bounds__(256) void k_bn_add_relu(size_t pixels, int C, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stem tail backward in ONE pass over the 256x256x64 gradient (instead of maxpool backward's read-modify-write followed by the
+// BN-backward reduce's read): g = (skip gradient + maxpool-backward gather) * [relu(bn(z)) > 0] is written back in place and
+// sum(g), sum(g*z) go to the replicated fp64 slabs, so the second phase is the pre-masked apply (mask_mode 0).
+// grid = (row segment, group of PB_ROWS rows, image); lanes along (w, channel vector).
+constexpr int PB_ROWS = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool_bwd_bn_reduce(int N, int H, int W, int C, const T* __restrict__ dpool,
+                                                               const uint8_t* __restrict__ argmax, const T* __restrict__ z,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               T* __restrict__ dy, double* sums) {
+  constexpr int VE = ElemTraits<T>::kVec;
+  const int Hp = H / 2, Wp = W / 2, CV = C / VE;
+  const int tid = threadIdx.x;
+  const unsigned t = blockIdx.x * blockDim.x + tid;
+  const bool active = t < (unsigned)(W * CV);
+  const int w = active ? (int)(t / (unsigned)CV) : 0, cv = active ? (int)(t - (unsigned)w * CV) : 0;
+  const int n = blockIdx.z;
+  float sc[VE], sh[VE], s1[VE], s2[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) {
+    sc[j] = scale[cv * VE + j];
+    sh[j] = shift[cv * VE + j];
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+  }
+  const int pw0 = (w & 1) ? (w - 1) / 2 : w / 2, npw = (w & 1) ? 2 : 1;
+  if (active) {
+    for (int hr = 0; hr < PB_ROWS; ++hr) {
+      const int h = blockIdx.y * PB_ROWS + hr;
+      if (h >= H) break;
+      const size_t i = (((size_t)n * H + h) * W + w) * CV + cv;
+      float g[VE], zf[VE];
+      Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(dy + i * VE), g);
+      Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(z + i * VE), zf);
+      const int ph0 = (h & 1) ? (h - 1) / 2 : h / 2, nph = (h & 1) ? 2 : 1;
+      float acc[VE];                       // pool contributions first, then one add: the summation order of k_maxpool_bwd
+#pragma unroll
+      for (int j = 0; j < VE; ++j) acc[j] = 0.f;
+      for (int a = 0; a < nph; ++a) {
+        const int ph = ph0 + a;
+        if (ph >= Hp) continue;
+        const int r = h - (2 * ph - 1);
+        for (int b = 0; b < npw; ++b) {
+          const int pw = pw0 + b;
+          if (pw >= Wp) continue;
+          const int code = r * 3 + (w - (2 * pw - 1));
+          const size_t pi = (((size_t)n * Hp + ph) * Wp + pw) * C + cv * VE;
+          uint32_t am[VE];
+          if (VE == 8) {
+            const u32x2_t q = *reinterpret_cast<const u32x2_t*>(argmax + pi);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) am[j] = (q[j >> 2] >> (8 * (j & 3))) & 0xffu;
+          } else {
+            const uint32_t q = *reinterpret_cast<const uint32_t*>(argmax + pi);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) am[j] = (q >> (8 * j)) & 0xffu;
+          }
+          float pg[VE];
+          Vec16<T>::unpack(*reinterpret_cast<const u32x4_t*>(dpool + pi), pg);
+#pragma unroll
+          for (int j = 0; j < VE; ++j)
+            if (am[j] == (uint32_t)code) acc[j] += pg[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VE; ++j) g[j] += acc[j];
+      // the unfused path rounds the sum to T when maxpool backward stores it; keep that rounding, then mask
+      u32x4_t v = Vec16<T>::pack(g);
+      Vec16<T>::unpack(v, g);
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        if (!(fmaf(zf[j], sc[j], sh[j]) > 0.f)) g[j] = 0.f;
+        s1[j] += g[j];
+        s2[j] += g[j] * zf[j];
+      }
+      *reinterpret_cast<u32x4_t*>(dy + i * VE) = Vec16<T>::pack(g);
+    }
+  }
+  // block reduction: thread (px, cv) -> channel sums over the block's pixels (as k_bn_bwd_reduce)
+  __shared__ float red[256 * 2 * 8];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) {
+    red[(tid * VE + j) * 2] = active ? s1[j] : 0.f;
+    red[(tid * VE + j) * 2 + 1] = active ? s2[j] : 0.f;
+  }
+  __syncthreads();
+  const int rows = 256 / CV;           // pixels per block (CV divides 256 for the channel counts on this path)
+  for (int c = tid; c < C; c += 256) {
+    const int ccv = c / VE, cj = c % VE;
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < rows; ++r) {
+      const int tt = r * CV + ccv;
+      a += red[(tt * VE + cj) * 2];
+      b += red[(tt * VE + cj) * 2 + 1];
+    }
+    double* sp = sums + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) % VK_STATS_REPLICAS) * 2 * C;
+    atomicAdd(sp + c, a);
+    atomicAdd(sp + C + c, b);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K13: BatchNorm (+ReLU) backward
 template <typename T, int MASK>
 __device__ __forceinline__ void masked_grad(const T* dy, const T* z, const T* mask_src, size_t off, const float* sc,
@@ -919,6 +1021,22 @@ extern "C" int vk_maxpool_bwd(vk_dtype dtype, int N, int H, int W, int C, const 
   VK_CHECK_ARG(N <= 65535 && H <= 65535 && H % 2 == 0 && W % 2 == 0, "vk_maxpool_bwd: N or H too large for the launch grid, or odd size");
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3((unsigned)((W * (C / ElemTraits<T>::kVec) + 255) / 256), (unsigned)H, (unsigned)N), dim3(256), 0, st,
                                        N, H, W, C, (const T*)dpool, argmax, (T*)dy));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_maxpool_bwd_bn_reduce(vk_dtype dtype, int N, int H, int W, int C, const void* dpool, const uint8_t* argmax, const void* z,
+                                        const float* scale, const float* shift, void* dy, double* sums, void* stream) {
+  VK_CHECK_ARG(dpool && argmax && z && scale && shift && dy && sums, "vk_maxpool_bwd_bn_reduce: null argument");
+  VK_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "vk_maxpool_bwd_bn_reduce: H, W even and C %% 8 == 0 required");
+  const int cv = C / (dtype == VK_F32 ? 4 : 8);
+  VK_CHECK_ARG(cv <= 256 && 256 % cv == 0, "vk_maxpool_bwd_bn_reduce: C=%d unsupported", C);
+  VK_CHECK_ARG(N <= 65535 && H <= 65535 * vk::PB_ROWS, "vk_maxpool_bwd_bn_reduce: N or H too large for the launch grid");
+  hipStream_t st = (hipStream_t)stream;
+  const double eb = dtype == VK_F32 ? 4.0 : 2.0;
+  vkh::ProfScope ps_("maxpool_bwd_bn_reduce", st, 0.0, (double)N * H * W * C * eb * 3.25 + (double)N * H * W * C / 4.0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_bwd_bn_reduce<T>, dim3((unsigned)((W * cv + 255) / 256), (unsigned)((H + PB_ROWS - 1) / PB_ROWS), (unsigned)N),
+                                       dim3(256), 0, st, N, H, W, C, (const T*)dpool, argmax, (const T*)z, scale, shift, (T*)dy, sums));
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }

@@ -1072,8 +1072,16 @@ int backward_stem(vk_unet* h, hipStream_t st) {
   const int N = h->cfg.N, S = h->cfg.size;
   ConvL& stem = h->convs[h->stem_conv];
   // stem.g holds the skip gradient of f1 (from decoder block 3); add the maxpool path
-  RET_IF(vk_maxpool_bwd(h->cfg.dtype, N, S / 2, S / 2, 64, h->ws + h->off_gpool, (const uint8_t*)(h->ws + h->off_argmax), stem.g, st));
-  RET_IF(bn_relu_bwd_inplace(h, stem, false, st));
+  if (getenv("VK_NO_POOL_BNR_FUSION")) {
+    RET_IF(vk_maxpool_bwd(h->cfg.dtype, N, S / 2, S / 2, 64, h->ws + h->off_gpool, (const uint8_t*)(h->ws + h->off_argmax), stem.g, st));
+    RET_IF(bn_relu_bwd_inplace(h, stem, false, st));
+  } else {
+    // one pass: maxpool backward + mask + BN-backward sums (saves a read-modify-write and a read of the 256x256x64 gradient)
+    BnL& b = h->bns[stem.bn];
+    RET_IF(vk_maxpool_bwd_bn_reduce(h->cfg.dtype, N, S / 2, S / 2, 64, h->ws + h->off_gpool, (const uint8_t*)(h->ws + h->off_argmax), stem.z,
+                                    b.scale, b.shift, stem.g, b.bsums, st));
+    RET_IF(bn_relu_bwd_inplace(h, stem, true, st));
+  }
   return vk_stem_wgrad(h->cfg.dtype, N, S, S, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, wgrad_stream(h, st));
 }
 
