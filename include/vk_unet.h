@@ -10,7 +10,8 @@
  *   vk_unet_loss .............................. bce(logits,y)+dice(logits,y) train.py:438, 513 (600-601)
  *   vk_unet_backward .......................... loss.backward()              train.py:443, 448
  *   vk_adamw_step ............................. optimizer.step()/zero_grad   train.py:428, 449 (606)
- *   vk_amp_check_inf .......................... GradScaler inf check          train.py:443-445 (610-611)
+ *   vk_amp_check_inf / vk_amp_unscale_check /
+ *   vk_adamw_step_amp ......................... GradScaler unscale + inf check + skipped step  train.py:441-445 (610-611)
  *   vk_conv_fwd / vk_conv_wgrad / ... ......... the ATen operators the reference dispatches to
  *                                               (conv2d, batch_norm, relu, max_pool2d, interpolate, cat)
  *   vk_conv_fwd_splitk ........................ the same convolutions at batch 1 (predict_mask / Segmenter.infer)
@@ -245,6 +246,22 @@ int vk_adamw_step(size_t n, float* param, const float* grad, float* exp_avg, flo
                   const int* found_inf, void* lowp_copy, vk_dtype lowp_dtype, void* stream);
 /* *found_inf |= any(!isfinite(grad)) */
 int vk_amp_check_inf(size_t n, const float* grad, int* found_inf, void* stream);
+
+/* The GradScaler protocol of the reference's CUDA branch (train.py:441-445, 610-611: scaler.scale(loss).backward();
+ * scaler.step(optimizer); scaler.update()) without a host round trip.  torch.amp.GradScaler keeps its scale and its
+ * found_inf flag as fp32 device scalars and hands them to an optimizer that declares _step_supports_amp_scaling:
+ *
+ * vk_amp_unscale_check = torch._amp_foreach_non_finite_check_and_unscale_ over the ONE flat gradient buffer:
+ *   grad *= *inv_scale (device fp32; NULL or a value of exactly 1 leaves the buffer unwritten), *found_inf = 1.0f if any
+ *   element is inf / nan (never cleared here: the caller zeroes it, as GradScaler does).  n % 4 == 0, grad 16-byte aligned.
+ * vk_adamw_step_amp = vk_adamw_step with everything step-dependent read on the device: *found_inf != 0 skips the update and
+ *   leaves *step_count (int32) as it is — GradScaler does not call optimizer.step() on an overflow; otherwise *step_count is
+ *   incremented first and drives the bias corrections, and the gradient is multiplied by inv_scale / *grad_scale
+ *   (grad_scale NULL: by inv_scale).  scratch4: float[4] device scratch owned by the caller. */
+int vk_amp_unscale_check(size_t n, float* grad, const float* inv_scale, float* found_inf, void* stream);
+int vk_adamw_step_amp(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int* step_count, float inv_scale, const float* grad_scale,
+                      const float* found_inf, float* scratch4, void* lowp_copy, vk_dtype lowp_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Engine level: the whole network as one plan

@@ -124,6 +124,8 @@ def test_c_abi_argument_errors(vk):
     assert L.vk_unet_tensor_info(h, 10_000, C.byref(ti)) < 0
     L.vk_unet_destroy(h)
     assert L.vk_adamw_step(0, None, None, None, None, 0.0, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None, None, 0, None) < 0
+    assert L.vk_adamw_step_amp(0, None, None, None, None, 0.0, 0.9, 0.999, 1e-8, 0.0, None, 1.0, None, None, None, None, 0, None) < 0
+    assert L.vk_amp_unscale_check(0, None, None, None, None) < 0
     # pre/post-processing descriptors are checked on the host before anything is launched
     lb = vk._lib.vk_letterbox_desc
     assert L.vk_letterbox_preprocess(None, None, None, None) < 0
@@ -143,6 +145,23 @@ def test_optimizer_is_a_torch_optimizer(vk):
     assert opt.param_groups[0]["lr"] == 5e-5 and opt.param_groups[0]["weight_decay"] == 1e-4
     lr_hist = json.load(open(GOLDEN / "lr_history.json"))["history.json"]["lr"]
     for e in range(3):
-        opt._step += 0           # (no device step on CPU) — the schedule itself is what is pinned here
         sch.step()
         assert opt.param_groups[0]["lr"] == pytest.approx(lr_hist[e], rel=1e-7)
+
+
+def test_optimizer_state_dict_is_not_mutated_and_amp_protocol_declared(vk):
+    """load_state_dict must not pop keys out of the caller's dict, loaded moments are kept (moved, never re-zeroed),
+    and the optimizer declares the GradScaler fast path (train.py:441-445)."""
+    m = vk.Unet(encoder_weights=None)
+    opt = vk.adamw_for(m, lr=5e-5, weight_decay=1e-4)
+    assert getattr(opt, "_step_supports_amp_scaling", False) is True
+    assert issubclass(vk.GradScaler, torch.amp.GradScaler)
+    n = m.flat_params.numel()
+    sd = opt.state_dict()
+    sd["fused"] = {"step": 7, "exp_avg": torch.full((n,), 0.25), "exp_avg_sq": torch.full((n,), 0.5)}
+    keys = set(sd)
+    opt2 = vk.adamw_for(m, lr=5e-5, weight_decay=1e-4)
+    opt2.load_state_dict(sd)
+    assert set(sd) == keys and "fused" in sd
+    assert opt2.step_count == 7 and float(opt2._m[0]) == 0.25 and float(opt2._v[-1]) == 0.5
+    assert opt2.state_dict()["fused"]["step"] == 7

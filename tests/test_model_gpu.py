@@ -353,3 +353,174 @@ def test_config3_bf16_train_bs32_512_properties():
         opt.step()
     assert losses[-1] < losses[0]
     assert int(model.state_dict()["encoder.bn1.num_batches_tracked"]) == 6
+
+
+# ------------------------------------------------------------------------------------------------ fp16 + GradScaler (train.py:431-445)
+def _oracle_amp_steps(O, batches, autocast: bool, init_scale: float = 65536.0):
+    """The reference's CUDA-branch step (train.py:431-445) restated on the CPU: fp16 autocast around forward + loss,
+    GradScaler scale / step / update.  autocast=False is the reference's CPU branch (fp32, no scaler)."""
+    O.set_seed(42)
+    ref = O.build_model()
+    ref.train()
+    opt = torch.optim.AdamW(ref.parameters(), lr=5e-5, weight_decay=1e-4)
+    scaler = torch.amp.GradScaler("cpu", init_scale=init_scale, enabled=autocast)
+    bce, dice = torch.nn.BCEWithLogitsLoss(), O.DiceLoss()
+    losses = []
+    for x, y in batches:
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cpu", dtype=torch.float16, enabled=autocast):
+            logits = ref(x)
+            loss = bce(logits.float(), y) + dice(logits.float(), y)     # autocast keeps the losses in fp32 (train.py:438)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(loss.item())
+    return ref, losses, scaler
+
+
+@pytest.mark.parametrize("scaler_kind", ["torch", "vk"])
+def test_amp_fp16_gradscaler_trajectory_vs_oracle(pair, scaler_kind):
+    """Three AMP steps through vk.train_one_epoch (fp16 autocast + GradScaler, the reference's own CUDA precision) against the
+    oracle: (i) fp32 (the reference's CPU branch) and (ii) the oracle under CPU fp16 autocast + GradScaler('cpu') — the
+    reference's own mixed-precision arithmetic on another backend.
+    Stated tolerances: per-step loss within 1e-2 relative of the fp32 oracle AND no further from it than 2x the autocast
+    oracle's own deviation + 2e-3; the update of encoder.conv1.weight (three Adam steps, |delta| <= 3 lr) agrees in direction
+    with the fp32 oracle's at least as well as the autocast oracle's does (cosine - 0.05) and every weight is within 3 lr;
+    BN running statistics within 2e-3; scale untouched (65536), three optimizer steps counted, no host-side unscale."""
+    O, _, _ = pair
+    x, y = O.synthetic_batch(6, 64, seed=21)
+    batches = [(x[i:i + 2], y[i:i + 2]) for i in (0, 2, 4)]
+    ref32, l32, _ = _oracle_amp_steps(O, batches, autocast=False)
+    ref16, l16, sc16 = _oracle_amp_steps(O, batches, autocast=True)
+    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
+    w0 = model.state_dict()["encoder.conv1.weight"].cpu().clone()
+    opt = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
+    scaler = (torch.amp.GradScaler if scaler_kind == "torch" else vk.GradScaler)("cuda", enabled=True)
+    lg = []
+    for xb, yb in batches:
+        lg.append(vk.train_one_epoch(model, [(xb, yb, ["a", "b"])], opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"),
+                                     "cuda", scaler))
+    assert scaler.get_scale() == 65536.0 == sc16.get_scale()
+    assert opt.step_count == 3
+    for i in range(3):
+        assert lg[i] == pytest.approx(l32[i], rel=1e-2), (lg, l32, l16)
+        assert abs(lg[i] - l32[i]) <= 2.0 * abs(l16[i] - l32[i]) + 2e-3, (lg, l32, l16)
+    wg = model.state_dict()["encoder.conv1.weight"].cpu()
+    w32 = ref32.state_dict()["encoder.conv1.weight"]
+    w16 = ref16.state_dict()["encoder.conv1.weight"]
+    assert not torch.equal(wg, w0)
+    assert (wg - w32).abs().max().item() <= 3 * 5e-5 * 1.05
+
+    def cos(a, b):
+        a, b = a.flatten().double(), b.flatten().double()
+        return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+
+    c_g, c_16 = cos(wg - w0, w32 - w0), cos(w16 - w0, w32 - w0)
+    assert c_g >= c_16 - 0.05, (c_g, c_16)
+    for k in ("encoder.bn1.running_mean", "decoder.blocks.4.conv2.1.running_var"):
+        a, b = model.state_dict()[k].cpu(), ref32.state_dict()[k]
+        assert (a - b).abs().max().item() <= 2e-3 * (1 + b.abs().max().item()), k
+
+
+@pytest.mark.parametrize("scaler_kind", ["torch", "vk"])
+def test_amp_overflow_step_is_skipped_and_scale_halves(pair, scaler_kind):
+    """A loss scale far too large (2^40) overflows the fp16 gradients: the step must be skipped on the DEVICE (weights, moments
+    and the step counter untouched bit for bit), GradScaler.update() must halve the scale exactly as torch does (backoff 0.5,
+    growth tracker reset), and training must recover once the scale has come down."""
+    O, _, _ = pair
+    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
+    opt = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
+    cls = torch.amp.GradScaler if scaler_kind == "torch" else vk.GradScaler
+    scaler = cls("cuda", init_scale=2.0 ** 40, growth_interval=2000, enabled=True)
+    x, y = O.synthetic_batch(2, 64, seed=5)
+    loader = [(x, y, ["a", "b"])]
+    before = model.flat_params.clone()
+    loss = vk.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
+    torch.cuda.synchronize()
+    assert np.isfinite(loss)                                   # the forward is fine; only the scaled gradients overflow
+    assert torch.equal(before, model.flat_params)              # skipped
+    assert opt.step_count == 0
+    assert scaler.get_scale() == 2.0 ** 39 and int(scaler._growth_tracker.item()) == 0
+    # the same overflow handled by torch itself on a plain module: identical scaler state
+    lin = torch.nn.Linear(4, 1).to(dev())
+    topt = torch.optim.AdamW(lin.parameters(), lr=5e-5)
+    ts = torch.amp.GradScaler("cuda", init_scale=2.0 ** 40, growth_interval=2000)
+    ts.scale(lin(torch.ones(1, 4, device=dev())).sum() * float("inf")).backward()
+    ts.step(topt); ts.update()
+    assert ts.get_scale() == scaler.get_scale() and int(ts._growth_tracker.item()) == int(scaler._growth_tracker.item())
+    # recovery: the scale keeps halving until the gradients fit, then steps are taken and counted
+    for _ in range(40):
+        vk.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
+        if opt.step_count >= 3:
+            break
+    assert opt.step_count >= 3 and scaler.get_scale() < 2.0 ** 30
+    assert not torch.equal(before, model.flat_params) and torch.isfinite(model.flat_params).all()
+
+
+def test_train_gradients_fp32_n8_against_plain_oracle(pair):
+    """All 140 parameter gradients against the UNMODIFIED oracle on a batch large enough that one ReLU tie cannot move a
+    BatchNorm channel (N=8, 128x128: >= 128 values per channel in the deepest layer): <= 1 % relative L2 per parameter."""
+    O, _, _ = pair
+    O.set_seed(42); ref = O.build_model()
+    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
+    x, y = O.synthetic_batch(8, 128, seed=77)
+    ref.train(); model.train()
+    O.total_loss(ref(x), y).backward()
+    lg = model(x.to(dev()))
+    (torch.nn.BCEWithLogitsLoss()(lg, y.to(dev())) + vk.DiceLoss(mode="binary")(lg, y.to(dev()))).backward()
+    torch.cuda.synchronize()
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        go = dict(ref.named_parameters())[k].grad
+        l2 = ((p.grad.cpu() - go).norm() / (go.norm() + 1e-12)).item()
+        if l2 > worst[1]:
+            worst = (k, l2)
+    print("worst relative L2 gradient error:", worst)
+    assert worst[1] <= 1e-2, worst
+
+
+def test_config5_fp16_train_bs8_1024_properties_and_eval_logits():
+    """BASELINE.json configs[4] workload on one GPU (fp16, bs 8, 1024x1024): the size-independent property set of configs[2]'s
+    test — finite loss in the expected band, bit-identical forward on repetition, reproducible slab-reduced weight gradients,
+    finite fp16 gradients under the reference's loss scale, loss decreasing over AdamW steps — plus an fp32 eval-logit check of
+    one 1024x1024 image against the CPU oracle (1e-4 relative: default running statistics, see configs[1]'s test)."""
+    from oracle import unet_oracle as O
+    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
+    opt = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
+    x, y = O.synthetic_batch(8, 1024, seed=1234)
+    xd, yd = x.to(dev()), y.to(dev())
+    model.eval()
+    O.set_seed(42); ref = O.build_model(); ref.eval()
+    with torch.no_grad():
+        lo = ref(x[:1])
+        lgc = model(xd[:1]).cpu()
+    assert (lgc - lo).abs().max().item() <= 1e-4 * lo.abs().max().item()
+    model.train()
+    opt.zero_grad(set_to_none=True)
+    l1 = model.loss_and_backward(xd, yd, dtype=torch.float16).clone()
+    lg1 = model.last_logits.clone()
+    g1 = model.flat_grads.clone()
+    opt.zero_grad(set_to_none=True)
+    l2 = model.loss_and_backward(xd, yd, dtype=torch.float16).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(l1).all() and 0.5 < l1[0].item() < 4.0
+    assert l1[0].item() == pytest.approx(l1[1].item() + l1[2].item(), rel=1e-6)
+    assert torch.equal(lg1, model.last_logits) and torch.equal(l1, l2)
+    assert torch.isfinite(g1).all()
+    name_to_off = {t[0]: (t[3], t[4]) for t in model._table}
+    for k in ("encoder.layer1.0.conv1.weight", "encoder.layer3.2.conv2.weight", "decoder.blocks.1.conv1.0.weight"):
+        o, n = name_to_off[k]
+        assert torch.equal(g1[o:o + n], model.flat_grads[o:o + n]), k
+    # the reference's loss scale (GradScaler default 2^16) through the fused path: scaled fp16 gradients stay finite at 1024x1024
+    opt.zero_grad(set_to_none=True)
+    model.loss_and_backward(xd, yd, grad_scale=65536.0, dtype=torch.float16)
+    gs = model.flat_grads
+    assert torch.isfinite(gs).all()
+    big = g1.abs() > 1e-3 * g1.abs().max()
+    assert ((gs / 65536.0 - g1).abs()[big] <= 0.05 * g1.abs()[big] + 1e-3 * g1.abs().max()).float().mean().item() > 0.99
+    losses = []
+    for _ in range(4):
+        opt.zero_grad(set_to_none=True)
+        losses.append(model.loss_and_backward(xd, yd, dtype=torch.float16)[0].item())
+        opt.step()
+    assert losses[-1] < losses[0]

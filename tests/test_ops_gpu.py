@@ -776,3 +776,65 @@ def test_adamw_matches_torch():
     vk._lib.check(vk.lib().vk_amp_check_inf(n, gd.data_ptr(), bad.data_ptr(), st()))
     torch.cuda.synchronize()
     assert bad.item() == 1
+
+
+def test_adamw_amp_device_protocol_matches_torch():
+    """vk_adamw_step_amp / vk_amp_unscale_check (reference train.py:441-445): scale, overflow flag and step counter are
+    read on the DEVICE.  Checked against torch.optim.AdamW driven the way GradScaler drives it: gradients divided by the scale, the
+    step not taken (and not counted) when any gradient is non-finite."""
+    n = 10240
+    g = torch.Generator().manual_seed(151)
+    p0 = torch.randn(n, generator=g)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=5e-5, weight_decay=1e-4)
+    pd = D(p0.clone())
+    m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    step = torch.zeros(1, dtype=torch.int32, device=dev())
+    scratch = torch.zeros(4, device=dev())
+    scale = torch.full((1,), 1024.0, device=dev())
+    found = torch.zeros(1, device=dev())
+    KEEP.extend([m, v, step, scratch, scale, found])
+    lib = vk.lib()
+
+    def run(gd, fi):
+        L_.check(lib.vk_adamw_step_amp(n, pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), 5e-5, 0.9, 0.999, 1e-8, 1e-4,
+                                       step.data_ptr(), 0.5, scale.data_ptr(), fi.data_ptr() if fi is not None else None,
+                                       scratch.data_ptr(), None, 0, st()))
+
+    for k in range(1, 6):
+        gr = torch.randn(n, generator=g)
+        overflow = k == 3
+        gd = D(gr * 2048.0)                    # gradient of (scale 1024) x (two ranks summed: inv_scale 0.5)
+        if overflow:
+            gd[123] = float("nan")
+        found.zero_()
+        L_.check(lib.vk_amp_unscale_check(n, gd.data_ptr(), None, found.data_ptr(), st()))
+        before = pd.clone()
+        run(gd, found)
+        torch.cuda.synchronize()
+        assert found.item() == (1.0 if overflow else 0.0)
+        if overflow:
+            assert torch.equal(before, pd)      # skipped: nothing written
+        else:
+            pr.grad = gr.clone()
+            opt.step()
+        assert step.item() == (k if k < 3 else k - 1)     # the skipped step is not counted (bias correction stays in phase)
+    assert (pd.cpu() - pr.detach()).abs().max().item() <= 2e-7
+    # in-place unscale: g *= *inv, and the check-only form (factor exactly 1) leaves the buffer untouched
+    gd = D(torch.randn(n, generator=g))
+    ref = gd.clone()
+    inv = torch.full((1,), 0.25, device=dev())
+    one = torch.ones(1, device=dev())
+    KEEP.extend([inv, one])
+    found.zero_()
+    L_.check(lib.vk_amp_unscale_check(n, gd.data_ptr(), one.data_ptr(), found.data_ptr(), st()))
+    torch.cuda.synchronize()
+    assert torch.equal(gd, ref) and found.item() == 0.0
+    L_.check(lib.vk_amp_unscale_check(n, gd.data_ptr(), inv.data_ptr(), found.data_ptr(), st()))
+    torch.cuda.synchronize()
+    assert torch.equal(gd, ref * 0.25) and found.item() == 0.0
+    gd[n - 1] = float("-inf")
+    L_.check(lib.vk_amp_unscale_check(n, gd.data_ptr(), inv.data_ptr(), found.data_ptr(), st()))
+    torch.cuda.synchronize()
+    assert found.item() == 1.0
+    assert lib.vk_amp_unscale_check(n - 1, gd.data_ptr(), None, found.data_ptr(), st()) < 0      # n % 4 != 0 is refused on the host

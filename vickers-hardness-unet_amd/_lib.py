@@ -90,6 +90,8 @@ SIGNATURES = {
     "vk_bce_dice_loss": (ci, [sz, vp, vp, vp, vp, vp, cf, cf, cf, vp]),
     "vk_adamw_step": (ci, [sz, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, cf, vp, vp, ci, vp]),
     "vk_amp_check_inf": (ci, [sz, vp, vp, vp]),
+    "vk_amp_unscale_check": (ci, [sz, vp, vp, vp, vp]),
+    "vk_adamw_step_amp": (ci, [sz, vp, vp, vp, vp, cf, cf, cf, cf, cf, vp, cf, vp, vp, vp, vp, ci, vp]),
     "vk_unet_create": (ci, [P(vk_unet_config), P(vp)]),
     "vk_unet_destroy": (None, [vp]),
     "vk_unet_set_side_stream": (ci, [vp, ci]),

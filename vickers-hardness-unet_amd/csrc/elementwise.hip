@@ -963,6 +963,66 @@ __global__ void k_check_inf(size_t n, const float* __restrict__ g, int* found) {
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(found, 1);
 }
 
+// K16, GradScaler form (torch._amp_foreach_non_finite_check_and_unscale_ over the ONE flat gradient buffer):
+// g *= *inv_scale (skipped when the factor is exactly 1: GradScaler's check-only call passes a dummy 1.0), *found_inf = 1.0f if any
+// element is inf / nan.  16-byte accesses; n4 = n / 4 (the flat buffer is padded to a multiple of 64 elements).
+__global__ __launch_bounds__(256) void k_amp_unscale_check(size_t n4, float* __restrict__ g, const float* __restrict__ inv_scale,
+                                                           float* __restrict__ found_inf) {
+  const float inv = inv_scale ? *inv_scale : 1.f;
+  const bool scale = inv != 1.f;
+  bool bad = false;
+  f32x4_t* g4 = reinterpret_cast<f32x4_t*>(g);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4_t v = g4[i];
+    bad |= !(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]));
+    if (scale) {
+      v = v * inv;
+      g4[i] = v;
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.f;     // every writer stores the same value
+}
+
+// One thread: resolves the GradScaler protocol on the device for k_adamw_dev (no host round trip, train.py:443-445).
+//   st[0] = skip flag (found_inf != 0), st[1] = lr / (1 - beta1^t), st[2] = sqrt(1 - beta2^t), st[3] = inv_scale / grad_scale;
+//   the step counter t advances only when the step is taken (torch: optimizer.step() is not called on an overflow).
+__global__ void k_adamw_prepare(int* __restrict__ step_count, const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
+                                float lr, float beta1, float beta2, float inv_scale, float* __restrict__ st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const bool skip = found_inf && *found_inf != 0.f;
+  int t = *step_count;
+  if (!skip) {
+    t += 1;
+    *step_count = t;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, (double)(t > 0 ? t : 1));
+  const double bc2 = 1.0 - pow((double)beta2, (double)(t > 0 ? t : 1));
+  st[0] = skip ? 1.f : 0.f;
+  st[1] = (float)((double)lr / bc1);
+  st[2] = (float)sqrt(bc2);
+  st[3] = grad_scale ? (float)((double)inv_scale / (double)*grad_scale) : inv_scale;
+}
+
+template <typename LT>
+__global__ void k_adamw_dev(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            float lr, float beta1, float beta2, float eps, float wd, const float* __restrict__ st, LT* lowp) {
+  if (st[0] != 0.f) return;
+  const float step_size = st[1], bc2_sqrt = st[2], inv_scale = st[3];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * inv_scale;
+    float pi = p[i] * (1.f - lr * wd);
+    float mi = m[i];
+    mi = mi + (gi - mi) * (1.f - beta1);
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - step_size * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (lowp) st1(lowp + i, pi);
+  }
+}
+
 }  // namespace vk
 
 // =================================================================================================
@@ -1241,6 +1301,37 @@ extern "C" int vk_adamw_step(size_t n, float* param, const float* grad, float* e
     hipLaunchKernelGGL(k_adamw<f16_t>, grid, block, 0, st, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
                        step_size, bc2_sqrt, inv_scale, found_inf, (f16_t*)lowp_copy);
   }
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_adamw_step_amp(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int* step_count, float inv_scale, const float* grad_scale,
+                                 const float* found_inf, float* scratch4, void* lowp_copy, vk_dtype lowp_dtype, void* stream) {
+  VK_CHECK_ARG(n > 0 && param && grad && exp_avg && exp_avg_sq && step_count && scratch4, "vk_adamw_step_amp: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_adamw_prepare, dim3(1), dim3(64), 0, st, step_count, grad_scale, found_inf, lr, beta1, beta2, inv_scale, scratch4);
+  vkh::ProfScope ps_("adamw", st, 0.0, (double)n * 28.0);
+  dim3 grid(grid_for(n)), block(256);
+  if (!lowp_copy || lowp_dtype == VK_F32) {
+    hipLaunchKernelGGL(k_adamw_dev<float>, grid, block, 0, st, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                       (const float*)scratch4, (float*)nullptr);
+  } else if (lowp_dtype == VK_BF16) {
+    hipLaunchKernelGGL(k_adamw_dev<bf16_t>, grid, block, 0, st, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                       (const float*)scratch4, (bf16_t*)lowp_copy);
+  } else {
+    hipLaunchKernelGGL(k_adamw_dev<f16_t>, grid, block, 0, st, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                       (const float*)scratch4, (f16_t*)lowp_copy);
+  }
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_amp_unscale_check(size_t n, float* grad, const float* inv_scale, float* found_inf, void* stream) {
+  VK_CHECK_ARG(n > 0 && grad && found_inf, "vk_amp_unscale_check: null argument");
+  VK_CHECK_ARG((n & 3) == 0 && ((uintptr_t)grad & 15) == 0, "vk_amp_unscale_check: the gradient buffer must be 16-byte aligned with n %% 4 == 0");
+  vkh::ProfScope ps_("amp_unscale_check", (hipStream_t)stream, 0.0, (double)n * 4.0);
+  hipLaunchKernelGGL(k_amp_unscale_check, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, n / 4, grad, inv_scale, found_inf);
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }
