@@ -11,6 +11,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                  FLOP/s (or B/s) from live HIP-event timing on the launch stream vs the gfx950 peak
   cpu_baseline : the oracle (torch CPU restatement of the reference path) timed on this host's cores
                  on a bounded sample (rank 0, N=1 only) — a reported baseline, never the target.
+and, beside `ms_per_step` (the fused step model.loss_and_backward + optimizer.step):
+  api_path_ms_per_step   : the drop-in path INTEGRATION.md describes — model(x) under torch.autocast, torch's BCEWithLogitsLoss +
+                           vk.DiceLoss, loss.backward() through autograd, optimizer.step() (GradScaler in fp16 mode)
+  sync_each_step_ms      : the same with `loss.item()` after every step, as the reference loop does (train.py:452)
 """
 import argparse
 import importlib
@@ -44,7 +48,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-variants", action="store_true", help="skip the 4-thread / bs 8 CPU baseline variant")
     ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--api-steps", type=int, default=10, help="timed steps of the drop-in API path (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,10 +94,15 @@ def main():
     if args.mode == "train":
         model.train()
 
+        # fp16 (configs[4]): the reference's loss scale (GradScaler default 2^16, train.py:610-611) — without it the 1024x1024
+        # gradients underflow in fp16; folded into the loss-gradient kernel and, as a device scalar, into the AdamW kernel
+        loss_scale = 65536.0 if dtype == torch.float16 else 1.0
+        scale_t = torch.full((1,), loss_scale, device=dev) if dtype == torch.float16 else None
+
         def step():
             opt.zero_grad(set_to_none=True)
-            out = model.loss_and_backward(x, y, dtype=dtype)
-            opt.step()
+            out = model.loss_and_backward(x, y, grad_scale=loss_scale, dtype=dtype)
+            opt.step(grad_scale=scale_t)
             return out
     else:
         model.eval()
@@ -128,17 +139,70 @@ def main():
         dt = t.item()
     last = [float(v) for v in out.flatten()[:3].tolist()] if args.mode == "train" else None
 
+    # ---- the same step through the drop-in API, and with the reference's per-step host sync
+    api_ms = sync_ms = None
+    if args.mode == "train" and args.api_steps > 0:
+        bce, dice = torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary")
+        scaler = vk.GradScaler("cuda", enabled=(dtype == torch.float16))
+
+        def step_api(sync):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=dtype, enabled=(dtype != torch.float32)):
+                logits = model(x)
+                loss = bce(logits, y) + dice(logits, y)
+            if dtype == torch.float16:                      # train.py:441-445
+                scaler.scale(loss).backward()
+                scaler.step(opt)
+                scaler.update()
+            else:                                           # train.py:448-449
+                loss.backward()
+                opt.step()
+            return loss.item() if sync else loss            # train.py:452
+
+        def timed(sync):
+            for _ in range(2):
+                step_api(sync)
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.api_steps):
+                step_api(sync)
+            torch.cuda.synchronize()
+            barrier()
+            d = time.perf_counter() - t1
+            if world > 1 or force_dist:
+                tt = torch.tensor([d], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                d = tt.item()
+            return d / args.api_steps * 1e3
+
+        api_ms = timed(False)
+        sync_ms = timed(True)
+        _log(f"drop-in API path: {api_ms:.2f} ms/step; with loss.item() every step: {sync_ms:.2f} ms/step")
+
     # ---- per-kernel-family timing with HIP events on the launch stream (a few extra, untimed-for-value steps)
     roof = None
     table = {}
     # EVERY rank runs these steps (they contain the gradient all-reduces: rank 0 alone would wait for its peers for ever);
     # only rank 0 brackets its launches with events and reports
     L = vk.lib()
+    dp_info = None
+    red = getattr(model, "_reducer", None)
+    if red is not None and args.mode == "train":
+        red.timing = True
     if rank == 0:
         L.vk_prof_enable(1)
     for _ in range(args.prof_steps):
         step()
     torch.cuda.synchronize()
+    if red is not None and args.mode == "train":
+        red.timing = False
+        tails = red.exposed_tail_ms()
+        plan = next(iter(model._plans.values()))
+        dp_info = {"buckets_mb_fp32": [round((b1 - b0) * 4 / 1e6, 2) for b0, b1 in plan.buckets],
+                   "exposed_allreduce_tail_ms": [round(t, 3) for t in tails],
+                   "note": "tail = time the compute stream waits for outstanding bucket all-reduces after its last backward "
+                           "kernel and before AdamW (HIP events on the compute stream, rank 0, profile steps)"}
     if rank == 0:
         L.vk_prof_enable(0)
         table = vk._lib.prof_collect()
@@ -167,12 +231,18 @@ def main():
                         "avg_launch_ms": round(per_launch_ms, 4)}
             # HBM traffic of the dominant kernel: offline rocprofv3 PMC measurement committed under profiles/ (bench.py itself
             # cannot run the profiler); null when that kernel family was not measured
+            roof["algorithmic_bytes_per_launch"] = round(r["bytes"] / r["n"])
             try:
-                tj = json.load(open(ROOT / "profiles" / "r01" / "traffic.json"))
-                if tag in tj:
+                tpath = ROOT / "profiles" / "r02" / "traffic.json"
+                tj = json.load(open(tpath))
+                here = kernel_source_hash()
+                if tj.get("_src_sha256") != here:
+                    roof["traffic_source"] = (f"{tpath.relative_to(ROOT)} was measured on kernel sources {str(tj.get('_src_sha256'))[:12]}, "
+                                              f"this tree is {here[:12]}: stale, not reported")
+                elif tag in tj:
                     roof["traffic"] = round(tj[tag]["fetch_bytes"] + tj[tag]["write_bytes"])
-                    roof["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py, mean per launch of the kernel symbol, FETCH doubled for gfx950)"
-                    roof["algorithmic_bytes_per_launch"] = round(r["bytes"] / r["n"])
+                    roof["traffic_source"] = (f"{tpath.relative_to(ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py, mean per "
+                                              f"launch of the kernel symbol, FETCH doubled for gfx950), measured on kernel sources {here[:12]} = this tree")
             except Exception:
                 pass
             tot = sum(v["ms"] for v in table.values())
@@ -213,6 +283,25 @@ def main():
         _log(f"cpu baseline done: {cdt / nst:.2f} s/step")
         cpu = {"value": round(bs * nst / cdt, 3), "unit": "images/s", "cores": cores, "kind": "port", "sample": sample,
                "cpu_model": _cpu_model()}
+        # the reference's own settings beside it: torch.set_num_threads(4) (train.py:19) and batch 8 (train.py:741)
+        if args.mode == "train" and not args.no_cpu_variants:
+            try:
+                torch.set_num_threads(min(4, cores))
+                x8, y8 = O.synthetic_batch(8, S, seed=1234)
+                O.set_seed(42)
+                ref4 = O.build_model(); ref4.train()
+                opt4 = torch.optim.AdamW(ref4.parameters(), lr=5e-5, weight_decay=1e-4)
+                O.train_steps(ref4, opt4, [(x8[:2], y8[:2])])        # warm-up (allocator, oneDNN primitives)
+                t1 = time.perf_counter()
+                O.train_steps(ref4, opt4, [(x8, y8)])
+                c4 = time.perf_counter() - t1
+                cpu["variants"] = [{"value": round(8 / c4, 3), "unit": "images/s", "cores": min(4, cores), "batch": 8,
+                                    "sample": f"1 fp32 train step at bs=8, {S}x{S}, torch.set_num_threads(4) as train.py:19, batch as "
+                                              f"train.py:741, after a bs=2 warm-up"}]
+                _log(f"cpu baseline (4 threads, bs 8): {8 / c4:.2f} img/s")
+                del ref4, opt4
+            finally:
+                torch.set_num_threads(cores)
         # ---- "mask IoU vs ref" (BASELINE.json metric, second half): the weights the timed steps left behind, loaded into the
         # oracle (same 278 state-dict keys), fp32 eval forward of both on the same images (reference validate(), train.py:495-529)
         try:
@@ -250,11 +339,26 @@ def main():
                        "parallelism": f"dp{world} (RCCL all-reduce of fp32 gradients, 10 buckets overlapped with backward)" if world > 1 else "single GPU"},
             "conv_tflops": round((TRAIN_GFLOP_PER_IMG_512 if args.mode == "train" else FWD_GFLOP_PER_IMG_512) * (S / 512) ** 2 * ips / 1e3, 2),
             "last_loss": last,
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "api_path_ms_per_step": None if api_ms is None else round(api_ms, 3),
+            "sync_each_step_ms": None if sync_ms is None else round(sync_ms, 3),
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "dp": dp_info,
         }
         print(json.dumps(rec), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources the library is built from (stable across rebuilds, unlike the .so): ties a committed
+    PMC traffic measurement to the code being benched."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted((ROOT / "vickers-hardness-unet_amd" / "csrc").glob("*.hip")) + sorted((ROOT / "vickers-hardness-unet_amd" / "csrc").glob("*.h")) \
+        + [ROOT / "include" / "vk_unet.h"]
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()
 
 
 def _log(msg):

@@ -19,6 +19,7 @@
  *                                               ui_infer_quadrilateral.py:197-216, 662-678; ui_infer_rectangle.py:225-245, 520-535
  *   vk_letterbox_postprocess_mask ............. sigmoid, threshold, un-letterbox  infer_pth_gui.py:26-29, 50-53
  *   vk_letterbox_postprocess_prob ............. sigmoid, un-letterbox, clip       ui_infer_quadrilateral.py:219-231, 705-711
+ *   vk_geom_minarearect ....................... postprocess_minarearect_multi      ui_infer_rectangle.py:291-381
  *
  * Conventions
  *   - plain pointers and sizes only; no C++/torch types cross this boundary.
@@ -175,6 +176,41 @@ int vk_letterbox_preprocess(const vk_letterbox_desc* d, const uint8_t* bgr, floa
 int vk_letterbox_postprocess_mask(const vk_letterbox_desc* d, const float* logits, float thresh, uint8_t* mask_hw, void* stream);
 /* logits [S][S] -> float32 [h][w] in [0,1]: sigmoid, crop, INTER_LINEAR back to the original size (copy when equal), clip */
 int vk_letterbox_postprocess_prob(const vk_letterbox_desc* d, const float* logits, float* prob_hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Geometry post-processing of batched probability maps: what the reference's GUIs do with
+ * Segmenter.infer's output to obtain the indentation diagonals — ui_infer_rectangle.py:291-381 postprocess_minarearect_multi
+ * (steps 1-3 are shared by ui_infer_quadrilateral.py:446-490): (prob >= bin_thresh) -> morphologyEx OPEN, CLOSE with the
+ * MORPH_ELLIPSE k x k element -> 8-connected components, area >= min_area -> per component the minimum-area enclosing rectangle
+ * (cv2.minAreaRect + boxPoints + astype(int32)) -> the two diagonals.  All steps run on the device for `batch` maps of one size.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int h, w;             /* size of every probability map (h <= 4096) */
+  float bin_thresh;     /* BIN_THRESH: 0.50 (rectangle GUI) / 0.45 (quadrilateral GUI); compared in float32 */
+  int morph_kernel;     /* MORPH_KERNEL: odd 1..7, side of the MORPH_ELLIPSE element (3 = cross); 1 = no morphology */
+  int open_iter;        /* OPEN_ITER */
+  int close_iter;       /* CLOSE_ITER */
+  int min_area;         /* max(200, int(MIN_AREA_FRAC * h * w)) in the reference (ui_infer_rectangle.py:322) */
+  int max_components;   /* capacity of the per-map detection list (further kept components stay in `clean` and in `counts`) */
+} vk_geom_desc;
+
+typedef struct {
+  int label;            /* connected-component id as cv2 / scipy number them: 1 + raster rank of the component's first pixel */
+  int area;             /* pixels */
+  int box[8];           /* x0,y0 .. x3,y3: rectangle corners truncated to int32 (order around the rectangle; not TL/TR/BR/BL) */
+  float cx, cy;         /* rectangle centre */
+  float rw, rh;         /* side lengths: along the supporting hull edge / across it */
+  float ux, uy;         /* unit direction of that edge */
+  int hull_n;           /* convex-hull vertices of the component */
+  int reserved;
+  double d1, d2, d_mean;/* diagonals of the int32 box (longest pair first) and their mean, float64 as numpy computes them */
+} vk_geom_det;
+
+int64_t vk_geom_workspace_bytes(const vk_geom_desc* d, int batch);      /* < 0: bad descriptor */
+/* prob: float32 [batch][h][w] in [0,1] (device).  clean: uint8 [batch][h][w] in {0,255}.  dets: [batch][max_components], filled in
+ * label order (the host sorts by area like ui_infer_rectangle.py:379).  counts: int32 [batch] = kept components per map. */
+int vk_geom_minarearect(const vk_geom_desc* d, int batch, const float* prob, uint8_t* clean, vk_geom_det* dets, int* counts,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* NCHW fp32 [N][3][H][W] -> NHWC4 `dtype` */
 int vk_input_transform(vk_dtype dtype, int N, int H, int W, const float* x, void* x4, void* stream);

@@ -119,6 +119,19 @@ def geometry_centered(h: int, w: int, size: int):
     return scale, nh, nw, (size - nh) // 2, (size - nw) // 2
 
 
+def geometry_train(h: int, w: int, size: int):
+    """train.py:70-75 (training) and the validation pipeline below it: A.LongestMaxSize(max_size=size, INTER_LINEAR) — [upstream]
+    albumentations scales the LONGEST side to exactly `size` (enlarging small images), new sizes py3round(dim * scale) — then
+    A.PadIfNeeded(size, size, border_mode=BORDER_CONSTANT): [upstream] default position "center", pad_top = int((size - nh) / 2.0),
+    fill value 0.  (The comment at train.py:72 says right/bottom; the library default is what runs.)  Returns (scale, nh, nw, top, left)."""
+    scale = size / max(h, w)
+    nh, nw = min(size, _pyround(h * scale)), min(size, _pyround(w * scale))
+    return scale, nh, nw, int((size - nh) / 2.0), int((size - nw) / 2.0)
+
+
+GEOMETRY = {"pad_br": geometry_pad_br, "centered": geometry_centered, "train": geometry_train}
+
+
 # ------------------------------------------------------------------------------------------------ pre-processing
 def letterbox(img_bgr: np.ndarray, size: int, nh: int, nw: int, top: int, left: int, pad_value: int = 0) -> np.ndarray:
     """resize + constant border -> uint8 [size, size, 3] (infer_pth_gui.py:21-23; ui_infer_quadrilateral.py:206-215)."""
@@ -135,9 +148,10 @@ def normalise_nchw(sq_bgr: np.ndarray) -> np.ndarray:
 
 
 def preprocess(img_bgr: np.ndarray, size: int, convention: str) -> tuple[np.ndarray, tuple]:
-    """-> (float32 [3, size, size], (nh, nw, top, left)); convention "pad_br" (infer_pth_gui) or "centered" (Qt wrappers)."""
+    """-> (float32 [3, size, size], (nh, nw, top, left)); convention "pad_br" (infer_pth_gui), "centered" (Qt wrappers) or
+    "train" (the dataset pipeline's LongestMaxSize + PadIfNeeded)."""
     h, w = img_bgr.shape[:2]
-    geo = geometry_pad_br(h, w, size) if convention == "pad_br" else geometry_centered(h, w, size)
+    geo = GEOMETRY[convention](h, w, size)
     _, nh, nw, top, left = geo
     return normalise_nchw(letterbox(img_bgr, size, nh, nw, top, left)), (nh, nw, top, left)
 

@@ -75,6 +75,12 @@ def _worker(rank, world, port, q):
     g2 = [torch.zeros_like(before) for _ in range(world)]
     dist.all_gather(g2, m2.flat_params)
     ok_bc = all(torch.equal(g2[0], t) for t in g2) and (rank == 0 or not torch.equal(before, m2.flat_params))
+    # C3: loss / metric scalars for logging (train.py:452-459 logs the mean loss): mean over ranks of [loss, dice, iou]
+    sc = vk.all_reduce_scalars(torch.tensor([float(loss), 0.25 * (rank + 1), 1.0]))
+    l_all = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(l_all, torch.tensor([float(loss)]))
+    ok_bc = ok_bc and abs(sc[0].item() - torch.stack(l_all).mean().item()) < 1e-6 and abs(sc[1].item() - 0.25 * (world + 1) / 2) < 1e-6 \
+        and sc[2].item() == 1.0
     q.put((rank, bool(ok_avg), bool(ok_sum), bool(ok_bc), float(loss)))
     dist.destroy_process_group()
 

@@ -68,12 +68,23 @@ def test_geometry_centered(h, w, size, want):
     assert P.geometry_centered(h, w, size) == pytest.approx(want)
 
 
+@pytest.mark.parametrize("h,w,size,want", [
+    (1200, 1600, 512, (0.32, 384, 512, 64, 0)),          # train.py:70-75 on a 1600x1200 micrograph
+    (300, 400, 512, (1.28, 384, 512, 64, 0)),            # LongestMaxSize enlarges (unlike the Qt wrappers' letterbox)
+    (1001, 333, 512, (512 / 1001, 512, 170, 0, 171)),
+    (2048, 3072, 512, (1 / 6, 341, 512, 85, 0)),         # the dataset's other size: 3072x2048 -> 512x341, 85 rows above, 86 below
+])
+def test_geometry_train(h, w, size, want):
+    assert P.geometry_train(h, w, size) == pytest.approx(want)
+
+
 def test_host_geometry_matches_oracle():
     vk = importlib.import_module("vickers-hardness-unet_amd")
     for h, w in [(1200, 1600), (300, 400), (1001, 333), (512, 512), (37, 2048), (1, 1)]:
         for size in (256, 512):
             assert vk.prepost.letterbox_geometry(h, w, size, "pad_br") == P.geometry_pad_br(h, w, size)
             assert vk.prepost.letterbox_geometry(h, w, size, "centered") == P.geometry_centered(h, w, size)
+            assert vk.prepost.letterbox_geometry(h, w, size, "train") == P.geometry_train(h, w, size)
     with pytest.raises(ValueError):
         vk.prepost.letterbox_geometry(10, 10, 512, "stretch")
 
@@ -93,9 +104,9 @@ def test_preprocess_layout_and_constants():
 def test_postprocess_roundtrip_shapes():
     rng = np.random.default_rng(1)
     lg = rng.normal(size=(64, 64)).astype(np.float32) * 4
-    for conv in ("pad_br", "centered"):
+    for conv in ("pad_br", "centered", "train"):
         for (h, w) in [(100, 150), (40, 30), (64, 64)]:
-            geo = (P.geometry_pad_br if conv == "pad_br" else P.geometry_centered)(h, w, 64)
+            geo = P.GEOMETRY[conv](h, w, 64)
             m = P.postprocess_mask(lg, *geo[1:], (h, w))
             pr = P.postprocess_prob(lg, *geo[1:], (h, w))
             assert m.shape == (h, w) and m.dtype == np.uint8 and set(np.unique(m)) <= {0, 255}

@@ -26,7 +26,7 @@ def _image(h, w, seed):
     return base
 
 
-@pytest.mark.parametrize("conv", ["pad_br", "centered"])
+@pytest.mark.parametrize("conv", ["pad_br", "centered", "train"])
 @pytest.mark.parametrize("h,w", SHAPES)
 @pytest.mark.parametrize("size", [512, 256])
 def test_preprocess_bit_exact(h, w, conv, size):
@@ -52,7 +52,7 @@ def test_preprocess_batch_and_pad_value():
 
 
 @pytest.mark.parametrize("kernel", ["per_pixel", "windowed", "auto"])
-@pytest.mark.parametrize("conv", ["pad_br", "centered"])
+@pytest.mark.parametrize("conv", ["pad_br", "centered", "train"])
 @pytest.mark.parametrize("h,w", SHAPES)
 def test_postprocess(h, w, conv, kernel, monkeypatch):
     if kernel == "auto":
@@ -63,7 +63,7 @@ def test_postprocess(h, w, conv, kernel, monkeypatch):
     rng = np.random.default_rng(h + 3 * w)
     lg = (rng.normal(size=(size, size)) * 3).astype(np.float32)
     lg[::7, ::5] = 0.0                      # exactly on the threshold: sigmoid(0) = 0.5 >= 0.5
-    geo = (P.geometry_pad_br if conv == "pad_br" else P.geometry_centered)(h, w, size)
+    geo = P.GEOMETRY[conv](h, w, size)
     meta = (geo[0], geo, (h, w))
     t = torch.from_numpy(lg).to(DEV)
     m = vk.prepost.postprocess_mask(t, meta, 0.5).cpu().numpy()

@@ -4,6 +4,9 @@
 Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM section): the counters are in KiB, FETCH_SIZE reports half of a
 wide coalesced streaming read on gfx950 and is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores."""
 import collections, csv, glob, json, re, sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 
 
 def family(name):
@@ -35,13 +38,15 @@ def main():
     res = {"_note": "HBM bytes per launch (mean over every launch of the kernel symbol in `bench.py --steps 2 --warmup 1`): rocprofv3 "
                     "--pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; counters are KiB; FETCH_SIZE doubled for gfx950 "
                     "(MI355X_MICROARCH.md, HBM section)."}
+    from bench import kernel_source_hash      # bench.py reports `traffic` only while this stamp matches the tree it runs on
+    res["_src_sha256"] = kernel_source_hash()
     for k in sorted(set(fe) | set(wr)):
         f = 2.0 * 1024.0 * sum(fe.get(k, [0])) / max(1, len(fe.get(k, [])))
         w = 1024.0 * sum(wr.get(k, [0])) / max(1, len(wr.get(k, [])))
         res[k] = {"fetch_bytes": round(f), "write_bytes": round(w), "launches": len(fe.get(k, []))}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print(f"{k:36s} fetch {v['fetch_bytes'] / 1e6:9.1f} MB  write {v['write_bytes'] / 1e6:9.1f} MB  n={v['launches']}")
 
 

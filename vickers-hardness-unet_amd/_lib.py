@@ -40,6 +40,17 @@ class vk_letterbox_desc(C.Structure):
                 ("nw", C.c_int), ("top", C.c_int), ("left", C.c_int), ("pad_value", C.c_int)]
 
 
+class vk_geom_desc(C.Structure):
+    _fields_ = [("h", C.c_int), ("w", C.c_int), ("bin_thresh", C.c_float), ("morph_kernel", C.c_int), ("open_iter", C.c_int),
+                ("close_iter", C.c_int), ("min_area", C.c_int), ("max_components", C.c_int)]
+
+
+class vk_geom_det(C.Structure):
+    _fields_ = [("label", C.c_int), ("area", C.c_int), ("box", C.c_int * 8), ("cx", C.c_float), ("cy", C.c_float),
+                ("rw", C.c_float), ("rh", C.c_float), ("ux", C.c_float), ("uy", C.c_float), ("hull_n", C.c_int),
+                ("reserved", C.c_int), ("d1", C.c_double), ("d2", C.c_double), ("d_mean", C.c_double)]
+
+
 class vk_unet_config(C.Structure):
     _fields_ = [("N", C.c_int), ("size", C.c_int), ("dtype", C.c_int), ("training", C.c_int)]
 
@@ -74,6 +85,8 @@ SIGNATURES = {
     "vk_letterbox_preprocess": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
     "vk_letterbox_postprocess_mask": (ci, [P(vk_letterbox_desc), vp, cf, vp, vp]),
     "vk_letterbox_postprocess_prob": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
+    "vk_geom_workspace_bytes": (i64, [P(vk_geom_desc), ci]),
+    "vk_geom_minarearect": (ci, [P(vk_geom_desc), ci, vp, vp, vp, vp, vp, sz, vp]),
     "vk_input_transform": (ci, [ci, ci, ci, ci, vp, vp, vp]),
     "vk_bn_finalize": (ci, [ci, ci, vp, cd, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
     "vk_bn_relu_maxpool": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),

@@ -86,6 +86,7 @@ struct HaloCfg {
   static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
   static_assert(WGM * WGN == 4 && TH % WGM == 0 && BN % (16 * WGN) == 0, "wave layout");
   static_assert(EPASS >= 1, "epilogue mapping");
+  static_assert(SMEM <= 160 * 1024, "main-loop / epilogue LDS image exceeds the 160 KiB of a CU");
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
@@ -545,6 +546,8 @@ struct ColCfg {
   static constexpr int EPI = BM * ESB + ESLOTS * BN * 2 * 4;     // + [wave x 16-lane row][channel][2] partial sums
   static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
   static_assert(TH % WGM == 0 && BN % (16 * WGN) == 0 && (NW == 4 || NW == 8), "wave layout");
+  static_assert(SMEM <= 160 * 1024, "main-loop / epilogue LDS image exceeds the 160 KiB of a CU");
+  static_assert(EPI >= BM * ESB + ESLOTS * BN * 8, "epilogue partial-sum slots must fit behind the output tile");
 };
 
 template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW>

@@ -11,7 +11,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -32,7 +34,9 @@ struct ProfRec {
   hipEvent_t a, b;
   double flops, bytes;
 };
-static bool g_prof_on = false;
+// guarded by g_prof_mu: the header promises re-entrant entry points (several host threads, one stream each)
+static std::mutex g_prof_mu;
+static std::atomic<bool> g_prof_on{false};
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 
@@ -47,20 +51,23 @@ static hipEvent_t prof_event() {
   return e;
 }
 
-ProfScope::ProfScope(const char* tag, hipStream_t stream, double flops, double bytes) : idx(-1), st(stream) {
-  if (!g_prof_on || g_recs.size() >= 200000) return;
+ProfScope::ProfScope(const char* tag, hipStream_t stream, double flops, double bytes) : idx(-1), st(stream), ev_end(nullptr) {
+  if (!g_prof_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_recs.size() >= 200000) return;
   ProfRec r{tag, prof_event(), prof_event(), flops, bytes};
   (void)hipEventRecord(r.a, st);
   idx = (int)g_recs.size();
+  ev_end = r.b;                       // the record vector may be reallocated by another thread before the destructor runs
   g_recs.push_back(r);
 }
 ProfScope::~ProfScope() {
-  if (idx >= 0) (void)hipEventRecord(g_recs[idx].b, st);
+  if (idx >= 0) (void)hipEventRecord(ev_end, st);
 }
 }  // namespace vkh
 
 extern "C" int vk_prof_enable(int on) {
-  vkh::g_prof_on = on != 0;
+  vkh::g_prof_on.store(on != 0);
   return VK_OK;
 }
 
@@ -68,6 +75,7 @@ extern "C" int vk_prof_collect(char* buf, size_t buflen) {
   using namespace vkh;
   struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
   std::map<std::string, Agg> agg;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (ProfRec& r : g_recs) {
     float ms = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -898,11 +906,15 @@ int bn_relu_bwd_inplace(vk_unet* h, ConvL& c, bool prereduced, hipStream_t st) {
 }
 
 // stream the weight-gradient kernels run on: the side stream, forked here behind everything enqueued on `st` so far
-hipStream_t wgrad_stream(vk_unet* h, hipStream_t st) {
-  if (!h->side) return st;
-  if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return st;
+// (a failed fork is an error of the call, never a silent fall-back onto the caller's stream)
+int wgrad_stream(vk_unet* h, hipStream_t st, hipStream_t* out) {
+  *out = st;
+  if (!h->side) return VK_OK;
+  VK_CHECK_HIP(hipEventRecord(h->ev_fork, st));
+  VK_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
   h->side_dirty = true;
-  return h->side;
+  *out = h->side;
+  return VK_OK;
 }
 
 int join_side(vk_unet* h, hipStream_t st) {
@@ -915,7 +927,9 @@ int join_side(vk_unet* h, hipStream_t st) {
 
 int conv_wgrad(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, hipStream_t st) {
   vk_conv_desc d = conv_desc(h, c, s0, s1);
-  return vk_conv_wgrad(&d, c.g, h->grads + c.w_off, h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, wgrad_stream(h, st));
+  hipStream_t ws;
+  RET_IF(wgrad_stream(h, st, &ws));
+  return vk_conv_wgrad(&d, c.g, h->grads + c.w_off, h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, ws);
 }
 
 vk_bnr bnr_of(vk_unet* h, ConvL& target) {     // fused BN+ReLU backward reduce descriptor for the layer `target`
@@ -1082,7 +1096,9 @@ int backward_stem(vk_unet* h, hipStream_t st) {
                                     b.scale, b.shift, stem.g, b.bsums, st));
     RET_IF(bn_relu_bwd_inplace(h, stem, true, st));
   }
-  return vk_stem_wgrad(h->cfg.dtype, N, S, S, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, wgrad_stream(h, st));
+  hipStream_t ws;
+  RET_IF(wgrad_stream(h, st, &ws));
+  return vk_stem_wgrad(h->cfg.dtype, N, S, S, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, ws);
 }
 
 int backward_stage(vk_unet* h, const float* dlogits, int stage, hipStream_t st) {

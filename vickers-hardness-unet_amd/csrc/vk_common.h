@@ -204,6 +204,7 @@ void set_error(const char* fmt, ...);
 struct ProfScope {
   int idx;
   hipStream_t st;
+  hipEvent_t ev_end;
   ProfScope(const char* tag, hipStream_t stream, double flops, double bytes);
   ~ProfScope();
 };

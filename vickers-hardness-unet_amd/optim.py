@@ -81,7 +81,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().zero_grad(set_to_none=True)
 
     @torch.no_grad()
-    def step(self, closure=None, found_inf: torch.Tensor | None = None):
+    def step(self, closure=None, found_inf: torch.Tensor | None = None, grad_scale: torch.Tensor | None = None):
         if closure is not None:
             raise NotImplementedError("closure is not used by the reference")
         m = self._find_model()
@@ -98,7 +98,9 @@ class FusedAdamW(torch.optim.Optimizer):
         grp = self.param_groups[0]
         # GradScaler support: torch sets these attributes around step() (device tensors; never read on the host here)
         fi = found_inf if found_inf is not None else getattr(self, "found_inf", None)
-        gs = getattr(self, "grad_scale", None)
+        gs = grad_scale if grad_scale is not None else getattr(self, "grad_scale", None)
+        if gs is not None and not isinstance(gs, torch.Tensor):
+            raise VkError("grad_scale must be a device tensor (a float here would have to come from a host sync)")
         if fi is not None:
             fi = fi.reshape(-1)[:1].to(device=p.device, dtype=torch.float32)
         if gs is not None:

@@ -32,6 +32,8 @@ class GradientReducer:
         self._handles: List = []
         self._ranges: List[Tuple[int, int]] = []
         self.enabled = self.world > 1 or force        # force: run the collectives even with one rank (testing)
+        self.timing = False                           # bench.py: bracket the wait for the collectives with two events
+        self._tail_events: List = []
 
     @property
     def inv_world(self) -> float:
@@ -48,14 +50,45 @@ class GradientReducer:
         self._ranges.append(rng)
 
     def finish(self):
+        timed = self.timing and self.enabled and self._handles and torch.cuda.is_available()
+        if timed:      # exposed tail = what the compute stream still has to wait for after its last backward kernel
+            e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e1.record()
         for h in self._handles:
             h.wait()
+        if timed:
+            e2.record()
+            self._tail_events.append((e1, e2))
         if self.enabled and self.scale_grads:
             g = self._get()
             for b0, b1 in self._ranges:
                 g[b0:b1].mul_(self.inv_world)
         self._handles.clear()
         self._ranges.clear()
+
+
+    def exposed_tail_ms(self) -> List[float]:
+        """Per step: time the compute stream waited for outstanding all-reduces after the last backward kernel (needs
+        ``timing = True``; synchronises)."""
+        out = []
+        for e1, e2 in self._tail_events:
+            e2.synchronize()
+            out.append(e1.elapsed_time(e2))
+        self._tail_events.clear()
+        return out
+
+
+def all_reduce_scalars(values: torch.Tensor, process_group=None, average: bool = True) -> torch.Tensor:
+    """loss / metric scalars for logging under data parallelism — the reference logs the sample-weighted mean loss
+    of its one process (train.py:452-459); with one process per GPU every rank holds its shard's value.  One small all-reduce
+    of a device tensor (no host sync here); returns the mean (or the sum) over ranks.  No-op without a process group."""
+    if not dist.is_initialized():
+        return values
+    out = values.detach().clone()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=process_group)
+    if average:
+        out /= dist.get_world_size(process_group)
+    return out
 
 
 def broadcast_model(model, src: int = 0, process_group=None):

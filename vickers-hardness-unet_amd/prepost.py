@@ -4,6 +4,7 @@ the device through libvkunet.so:
     reference                                              here
     infer_pth_gui.letterbox_pad / predict_mask ........... letterbox_geometry(..., "pad_br"), predict_mask
     ui_infer_*.letterbox_square / Segmenter.preprocess ... letterbox_geometry(..., "centered"), Segmenter.preprocess
+    train.py LongestMaxSize + PadIfNeeded (train/val) .... letterbox_geometry(..., "train")
     infer_pth_gui.unpad_and_resize_mask .................. postprocess_mask
     ui_infer_*.unletterbox / Segmenter.infer ............. postprocess_prob, Segmenter.infer
 
@@ -27,13 +28,20 @@ def letterbox_geometry(h: int, w: int, size: int, convention: str = "centered") 
     """Where the resized image sits in the size x size square.
 
     "pad_br"   infer_pth_gui.py:17-24: scale = min(size/h, size/w) (may enlarge), image top-left, zeros right/below.
-    "centered" ui_infer_quadrilateral.py:197-216, ui_infer_rectangle.py:225-245: scale = min(size/max(h,w), 1), centred."""
+    "centered" ui_infer_quadrilateral.py:197-216, ui_infer_rectangle.py:225-245: scale = min(size/max(h,w), 1), centred.
+    "train"    train.py:70-75 (and the validation pipeline below it): albumentations LongestMaxSize(max_size=size) — scale =
+               size/max(h,w), may enlarge, new size rounded half-to-even — then PadIfNeeded(size, size, BORDER_CONSTANT), whose
+               default position is the centre (top = (size-nh)//2, left = (size-nw)//2), value 0."""
     if convention == "pad_br":
         scale = min(size / h, size / w)
         return scale, int(round(h * scale)), int(round(w * scale)), 0, 0
     if convention == "centered":
         scale = min(size / max(h, w), 1.0)
         nh, nw = int(round(h * scale)), int(round(w * scale))
+        return scale, nh, nw, (size - nh) // 2, (size - nw) // 2
+    if convention == "train":
+        scale = size / max(h, w)
+        nh, nw = min(size, int(round(h * scale))), min(size, int(round(w * scale)))
         return scale, nh, nw, (size - nh) // 2, (size - nw) // 2
     raise ValueError(f"unknown letterbox convention {convention!r}")
 
