@@ -20,6 +20,7 @@
  *   vk_letterbox_postprocess_mask ............. sigmoid, threshold, un-letterbox  infer_pth_gui.py:26-29, 50-53
  *   vk_letterbox_postprocess_prob ............. sigmoid, un-letterbox, clip       ui_infer_quadrilateral.py:219-231, 705-711
  *   vk_geom_minarearect ....................... postprocess_minarearect_multi      ui_infer_rectangle.py:291-381
+ *   vk_letterbox_u8 / _mask_u8 / vk_augment_batch  VickersDataset.__getitem__ + albumentations pipeline  train.py:67-113, 173-200
  *
  * Conventions
  *   - plain pointers and sizes only; no C++/torch types cross this boundary.
@@ -211,6 +212,33 @@ int64_t vk_geom_workspace_bytes(const vk_geom_desc* d, int batch);      /* < 0: 
  * label order (the host sorts by area like ui_infer_rectangle.py:379).  counts: int32 [batch] = kept components per map. */
 int vk_geom_minarearect(const vk_geom_desc* d, int batch, const float* prob, uint8_t* clean, vk_geom_det* dets, int* counts,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training-time augmentation on the device: VickersDataset.__getitem__ (train.py:173-200) with the
+ * albumentations pipeline of train.py:67-113.  The dataset is letterboxed ONCE into uint8 tensors that stay in HBM
+ * (vk_letterbox_u8 / vk_letterbox_mask_u8: LongestMaxSize + PadIfNeeded, train.py:70-75, geometry in the descriptor); every
+ * step vk_augment_batch turns n dataset items + n sets of random draws (made by the host, as albumentations makes them) into
+ * the network input x float32 [n][3][S][S] and target y float32 [n][1][S][S] in one fused pass.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int d4;               /* OneOf(flips, rot90), train.py:81-85: 0 none, 1 HorizontalFlip, 2 VerticalFlip, 3 + k = np.rot90(k), k = 0..3 */
+  int rotate;           /* Rotate(limit=180, BORDER_CONSTANT), train.py:89: 1 = applied */
+  float cos_a, sin_a;   /* of the angle (counter-clockwise, cv2.getRotationMatrix2D about (S/2 - 0.5, S/2 - 0.5)) */
+  int photo;            /* OneOf, train.py:96-100: 0 none, 1 RandomBrightnessContrast, 3 GaussianBlur (2 = CLAHE: refused) */
+  float alpha, beta;    /* RandomBrightnessContrast: v' = trunc(clip(v * alpha + beta * 255, 0, 255)) */
+  int blur_ksize;       /* GaussianBlur: 3 or 5 (sigma 0 -> cv2's binomial kernels), BORDER_REFLECT_101 */
+  float noise_scale;    /* GaussNoise, train.py:104: sigma / 65536 on the 0..255 scale; 0 = not applied */
+  uint32_t noise_seed;  /* seed of the counter-based noise field of this sample */
+} vk_aug_params;
+
+/* uint8 BGR [h][w][3] -> uint8 RGB [S][S][3]: cv2.resize(INTER_LINEAR) to nh x nw at (top, left), constant border */
+int vk_letterbox_u8(const vk_letterbox_desc* d, const uint8_t* bgr, uint8_t* rgb_sq, void* stream);
+/* uint8 mask [h][w] (row stride d->src_stride bytes) -> {0,1} [S][S]: (m > 0), cv2.resize(INTER_NEAREST), border 0 */
+int vk_letterbox_mask_u8(const vk_letterbox_desc* d, const uint8_t* mask_hw, uint8_t* mask_sq, void* stream);
+/* images_rgb uint8 [n_items][S][S][3], masks uint8 [n_items][S][S] in {0,1} (device); index_dev int32 [n] (device): the dataset
+ * item of every sample; params_host [n]: validated on the host, then copied to params_dev (device scratch, n * sizeof) */
+int vk_augment_batch(int n, int size, int n_items, const uint8_t* images_rgb, const uint8_t* masks, const int* index_dev,
+                     const vk_aug_params* params_host, void* params_dev, float* x, float* y, void* stream);
 
 /* NCHW fp32 [N][3][H][W] -> NHWC4 `dtype` */
 int vk_input_transform(vk_dtype dtype, int N, int H, int W, const float* x, void* x4, void* stream);

@@ -1,0 +1,108 @@
+"""CPU tests of the augmentation oracle (oracle/augment_oracle.py) and the host sampler: albumentations / cv2 are absent, so the
+restatement of train.py:67-113 is pinned to properties that hold for the real transforms whatever their round-off: flips and
+rot90 are permutations, Rotate(+90 deg) is np.rot90 (counter-clockwise, centre (S/2 - 0.5)), the blur kernels are cv2's binomial
+ones, RandomBrightnessContrast is its LUT formula, the noise field has the requested moments, Normalize is the library's formula;
+the sampler reproduces the pipeline's probabilities and ranges."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+
+from oracle import augment_oracle as A
+
+
+def _img(S, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (S, S, 3), dtype=np.uint8), (rng.random((S, S)) > 0.7).astype(np.uint8)
+
+
+def test_d4_members_are_the_numpy_permutations():
+    im, mk = _img(12, 0)
+    assert np.array_equal(A.apply_d4(im, A.D4_HFLIP), im[:, ::-1]) and np.array_equal(A.apply_d4(im, A.D4_VFLIP), im[::-1])
+    for k in range(4):
+        assert np.array_equal(A.apply_d4(mk, A.D4_ROT90_0 + k), np.rot90(mk, k))
+    assert A.apply_d4(im, 0) is im
+
+
+@pytest.mark.parametrize("S", [16, 33])
+def test_rotate_by_quarter_turns_is_rot90(S):
+    """cv2.getRotationMatrix2D: positive angle = counter-clockwise about (S/2 - 0.5, S/2 - 0.5): +90 deg == np.rot90(k=1)."""
+    im, mk = _img(S, 1)
+    for k, (c, s) in enumerate([(1.0, 0.0), (0.0, 1.0), (-1.0, 0.0), (0.0, -1.0)]):
+        ri, rm = A.rotate(im, mk, c, s)
+        assert np.array_equal(ri, np.rot90(im, k)) and np.array_equal(rm, np.rot90(mk, k))
+
+
+def test_rotate_keeps_the_centre_and_blackens_the_corners():
+    S = 64
+    im = np.full((S, S, 3), 200, dtype=np.uint8)
+    mk = np.ones((S, S), dtype=np.uint8)
+    a = math.radians(45.0)
+    ri, rm = A.rotate(im, mk, math.cos(a), math.sin(a))
+    assert (ri[S // 2 - 4:S // 2 + 4, S // 2 - 4:S // 2 + 4] == 200).all() and rm[S // 2, S // 2] == 1
+    assert (ri[0, 0] == 0).all() and rm[0, 0] == 0 and (ri[-1, -1] == 0).all()          # BORDER_CONSTANT 0
+    assert 0.74 < rm.mean() < 0.84                                                       # octagon area 0.828 minus the edge taps
+
+
+def test_blur_kernels_are_opencv_s_binomials():
+    im = np.zeros((15, 15, 3), dtype=np.uint8)
+    im[7, 7] = 255
+    b3, b5 = A.gaussian_blur(im, 3)[..., 0].astype(int), A.gaussian_blur(im, 5)[..., 0].astype(int)
+    k3 = np.outer([1, 2, 1], [1, 2, 1]) * 255
+    k5 = np.outer([1, 4, 6, 4, 1], [1, 4, 6, 4, 1]) * 255
+    assert np.array_equal(b3[6:9, 6:9], (k3 + 8) // 16) and np.array_equal(b5[5:10, 5:10], (k5 + 128) // 256)
+    flat = np.full((9, 9, 3), 77, dtype=np.uint8)
+    assert (A.gaussian_blur(flat, 5) == 77).all()                   # REFLECT_101 border keeps a constant image constant
+    ramp = np.tile(np.arange(9, dtype=np.uint8)[None, :, None] * 10, (9, 1, 3))
+    assert A.gaussian_blur(ramp, 3)[4, 0, 0] == (2 * 0 + 2 * 10 + 2) // 4          # column -1 reflects to column 1
+
+
+def test_brightness_contrast_lut():
+    im = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, axis=2)
+    assert np.array_equal(A.brightness_contrast(im, 1.0, 0.0), im)
+    out = A.brightness_contrast(im, 1.2, -0.1)
+    want = np.clip(np.arange(256, dtype=np.float32) * np.float32(1.2) + np.float32(-0.1) * np.float32(255), 0, 255).astype(np.uint8)
+    assert np.array_equal(out[..., 0].ravel(), want) and out.max() == 255 and out.min() == 0
+
+
+def test_noise_field_moments_and_determinism():
+    S = 96
+    s = A.noise_isum(1234, S).astype(np.float64)
+    z = (s - 393210.0) / 65536.0
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02 and np.abs(z).max() < 6.0
+    assert abs(np.mean(z ** 4) - 3.0) < 0.25                                           # Irwin-Hall(12): kurtosis 2.9
+    assert np.array_equal(A.noise_isum(1234, S), A.noise_isum(1234, S)) and not np.array_equal(A.noise_isum(1234, S), A.noise_isum(1235, S))
+    assert abs(np.corrcoef(z[..., 0].ravel(), z[..., 1].ravel())[0, 1]) < 0.03          # channels independent (per_channel=True)
+    im = np.full((S, S, 3), 128, dtype=np.uint8)
+    sig = math.sqrt(30.0)
+    d = A.gauss_noise(im, sig / 65536.0, 7).astype(np.float64) - 128.0
+    assert abs(d.std() - sig) < 0.35 and abs(d.mean() + 0.5) < 0.3                      # truncation towards zero costs half a level
+
+
+def test_normalize_is_the_library_formula():
+    im, _ = _img(8, 3)
+    x = A.normalize_chw(im)
+    ref = (im.astype(np.float64) / 255.0 - A.MEAN.astype(np.float64)) / A.STD.astype(np.float64)
+    assert x.shape == (3, 8, 8) and x.dtype == np.float32 and np.abs(x - ref.transpose(2, 0, 1)).max() < 1e-5
+
+
+def test_sampler_reproduces_the_pipeline_probabilities():
+    vk = importlib.import_module("vickers-hardness-unet_amd")
+    sm = vk.AugmentSampler(seed=0)
+    n = 20000
+    ds = [sm.sample() for _ in range(n)]
+    frac = lambda f: sum(1 for d in ds if f(d)) / n       # noqa: E731
+    assert abs(frac(lambda d: d["d4"] != 0) - 0.8) < 0.015                    # OneOf p=0.8 (rot90 factor 0 still counts as drawn)
+    assert abs(frac(lambda d: d["d4"] == 1) - 0.8 / 3) < 0.015 and abs(frac(lambda d: d["d4"] >= 3) - 0.8 / 3) < 0.015
+    assert abs(frac(lambda d: d["rotate"] == 1) - 0.6) < 0.015
+    assert abs(frac(lambda d: d["photo"] != 0) - 0.8) < 0.015 and frac(lambda d: d["photo"] == 2) == 0.0
+    assert abs(frac(lambda d: d["noise_scale"] > 0) - 0.3) < 0.015
+    al = [d["alpha"] for d in ds if d["photo"] == 1]
+    assert 0.8 <= min(al) and max(al) <= 1.2 and all(-0.2 <= d["beta"] <= 0.2 for d in ds)
+    sg = [d["noise_scale"] * 65536 for d in ds if d["noise_scale"] > 0]
+    assert math.sqrt(10) <= min(sg) and max(sg) <= math.sqrt(50)
+    assert all(abs(d["cos_a"] ** 2 + d["sin_a"] ** 2 - 1) < 1e-12 for d in ds)
+    none = vk.AugmentSampler(seed=0, clahe="none")
+    assert abs(sum(1 for _ in range(n) if none.sample()["photo"] != 0) / n - 0.8 * 2 / 3) < 0.02
+    assert {d["blur_ksize"] for d in ds if d["photo"] == 3} == {3, 5}

@@ -1,0 +1,129 @@
+"""Device dataset + fused augmentation kernel (-m gpu) against oracle/augment_oracle.py and oracle/prepost_oracle.py:
+byte / index work and float32 arithmetic in a fixed order, so every comparison is EXACT (np.array_equal)."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment_oracle as A
+from oracle import prepost_oracle as P
+
+pytestmark = pytest.mark.gpu
+vk = importlib.import_module("vickers-hardness-unet_amd")
+DEV = torch.device("cuda:0")
+
+
+def _raw(h, w, seed):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img[..., 1] = ((yy * 3 + xx * 2) % 256).astype(np.uint8)
+    mask = ((np.abs(xx - w / 2) + np.abs(yy - h / 2)) < min(h, w) / 4).astype(np.uint8) * rng.integers(1, 256, dtype=np.uint8)
+    return img, mask
+
+
+def _oracle_letterbox(img_bgr, mask, S):
+    h, w = img_bgr.shape[:2]
+    _, nh, nw, top, left = P.geometry_train(h, w, S)
+    sq = P.letterbox(img_bgr, S, nh, nw, top, left)[:, :, ::-1]                       # BGR -> RGB (train.py:149)
+    m = np.zeros((S, S), dtype=np.uint8)
+    m[top:top + nh, left:left + nw] = P.resize_nearest((mask > 0).astype(np.uint8), nw, nh)
+    return np.ascontiguousarray(sq), m
+
+
+DRAWS = [
+    dict(A_d4=0),
+    dict(A_d4=1), dict(A_d4=2), dict(A_d4=3), dict(A_d4=4), dict(A_d4=5), dict(A_d4=6),
+    dict(rot=30.0), dict(rot=-137.5), dict(rot=90.0), dict(rot=180.0), dict(A_d4=4, rot=12.25),
+    dict(photo=1, alpha=1.17, beta=-0.08), dict(photo=1, alpha=0.81, beta=0.2),
+    dict(photo=3, k=3), dict(photo=3, k=5), dict(A_d4=2, rot=-61.0, photo=3, k=5),
+    dict(noise=math.sqrt(10.0), seed=1), dict(noise=math.sqrt(50.0), seed=4_000_000_000),
+    dict(A_d4=5, rot=77.0, photo=1, alpha=0.9, beta=0.1, noise=5.0, seed=99), dict(A_d4=1, rot=-15.0, photo=3, k=3, noise=6.5, seed=3),
+]
+
+
+def _draw(spec):
+    d = dict(vk.augment.IDENTITY)
+    d["d4"] = spec.get("A_d4", 0)
+    if "rot" in spec:
+        a = math.radians(spec["rot"])
+        d.update(rotate=1, cos_a=math.cos(a), sin_a=math.sin(a))
+    if "photo" in spec:
+        d.update(photo=spec["photo"], alpha=spec.get("alpha", 1.0), beta=spec.get("beta", 0.0), blur_ksize=spec.get("k", 3))
+    if "noise" in spec:
+        d.update(noise_scale=spec["noise"] / 65536.0, noise_seed=spec["seed"])
+    return d
+
+
+@pytest.fixture(scope="module")
+def dataset():
+    shapes = [(120, 160), (307, 205), (96, 96), (64, 200)]
+    raws = [_raw(h, w, i) for i, (h, w) in enumerate(shapes)]
+    ds = vk.DeviceDataset([r[0] for r in raws], [r[1] for r in raws], img_size=96, device=DEV, names=["a", "b", "c", "d"])
+    return raws, ds
+
+
+def test_dataset_letterbox_is_bit_exact(dataset):
+    raws, ds = dataset
+    assert len(ds) == 4 and ds.images.shape == (4, 96, 96, 3) and ds.masks.dtype == torch.uint8
+    for i, (img, mask) in enumerate(raws):
+        sq, m = _oracle_letterbox(img, mask, 96)
+        assert np.array_equal(ds.images[i].cpu().numpy(), sq), i
+        assert np.array_equal(ds.masks[i].cpu().numpy(), m), i
+        assert set(np.unique(m)) <= {0, 1}
+
+
+def test_validation_pipeline_is_normalize_only(dataset):
+    raws, ds = dataset
+    x, y, names = ds.batch([2, 0])
+    assert names == ["c", "a"] and x.shape == (2, 3, 96, 96) and y.shape == (2, 1, 96, 96)
+    for j, i in enumerate([2, 0]):
+        sq, m = _oracle_letterbox(*raws[i], 96)
+        assert np.array_equal(x[j].cpu().numpy(), A.normalize_chw(sq))
+        assert np.array_equal(y[j, 0].cpu().numpy(), m.astype(np.float32))
+
+
+def test_every_transform_is_bit_exact(dataset):
+    raws, ds = dataset
+    draws = [_draw(s) for s in DRAWS]
+    idx = [i % 4 for i in range(len(draws))]
+    x, y, _ = ds.batch(idx, draws=draws)
+    xs, ys = x.cpu().numpy(), y.cpu().numpy()
+    for j, (i, d) in enumerate(zip(idx, draws)):
+        sq, m = _oracle_letterbox(*raws[i], 96)
+        xo, yo = A.augment(sq, m, d)
+        assert np.array_equal(ys[j], yo), (j, DRAWS[j])
+        assert np.array_equal(xs[j], xo), (j, DRAWS[j], np.abs(xs[j] - xo).max())
+
+
+def test_full_size_batch_with_sampled_draws():
+    """512x512, 32 samples drawn by the sampler (the reference's batch shape, train.py:741 x 4): exact against the oracle."""
+    raws = [_raw(600, 800, 10), _raw(1024, 768, 11)]
+    ds = vk.DeviceDataset([r[0] for r in raws], [r[1] for r in raws], img_size=512, device=DEV)
+    sm = vk.AugmentSampler(seed=5)
+    draws = [sm.sample() for _ in range(32)]
+    idx = [i % 2 for i in range(32)]
+    x, y, _ = ds.batch(idx, draws=draws)
+    assert torch.isfinite(x).all() and set(torch.unique(y).tolist()) <= {0.0, 1.0}
+    sq = [_oracle_letterbox(*r, 512) for r in raws]
+    for j in (0, 5, 13, 31):
+        xo, yo = A.augment(*sq[idx[j]], draws[j])
+        assert np.array_equal(x[j].cpu().numpy(), xo) and np.array_equal(y[j].cpu().numpy(), yo), (j, draws[j])
+    # loader protocol: (x, y, names) like DataLoader(VickersDataset) (train.py:423)
+    batches = list(ds.loader(batch_size=2, shuffle=True, sampler=sm, seed=1))
+    assert len(batches) == 1 and batches[0][0].shape == (2, 3, 512, 512) and len(batches[0][2]) == 2
+
+
+def test_argument_errors(dataset):
+    _, ds = dataset
+    bad = dict(vk.augment.IDENTITY, photo=2)                     # CLAHE: refused, never silently skipped
+    with pytest.raises(vk.VkError, match="CLAHE"):
+        ds.batch([0], draws=[bad])
+    with pytest.raises(vk.VkError):
+        ds.batch([0], draws=[dict(vk.augment.IDENTITY, photo=3, blur_ksize=4)])
+    with pytest.raises(vk.VkError):
+        vk.DeviceDataset([np.zeros((4, 4, 3), np.uint8)], [np.zeros((4, 4), np.uint8)], device="cpu")
+    x, _, _ = ds.batch([99])                                     # out-of-range item index is clamped on the device, never read out of bounds
+    assert torch.isfinite(x).all()

@@ -10,7 +10,8 @@ Import by string (the directory name carries hyphens)::
     optimizer = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
 
 Everything heavy runs in libvkunet.so (hand-written HIP); there is no CPU fallback."""
-from . import _lib, geometry, losses, metrics, parallel, prepost  # noqa: F401
+from . import _lib, augment, geometry, losses, metrics, parallel, prepost  # noqa: F401
+from .augment import AugmentSampler, DeviceDataset  # noqa: F401
 from .geometry import postprocess_minarearect_batch, postprocess_minarearect_multi  # noqa: F401
 from ._lib import VkError, build, lib  # noqa: F401
 from .losses import BCEDiceLoss, DiceLoss  # noqa: F401
@@ -23,5 +24,5 @@ from .unet import Unet, build_model  # noqa: F401
 
 __all__ = ["Unet", "build_model", "DiceLoss", "BCEDiceLoss", "FusedAdamW", "GradScaler", "adamw_for", "GradientReducer",
            "make_data_parallel", "broadcast_model", "all_reduce_scalars", "dice_coef", "iou_coef", "train_one_epoch", "validate",
-           "VkError", "build", "lib", "losses", "metrics", "parallel", "prepost", "Segmenter", "predict_mask", "geometry",
+           "VkError", "build", "lib", "losses", "metrics", "parallel", "prepost", "Segmenter", "predict_mask", "geometry", "augment", "AugmentSampler", "DeviceDataset",
            "postprocess_minarearect_multi", "postprocess_minarearect_batch"]

@@ -51,6 +51,12 @@ class vk_geom_det(C.Structure):
                 ("reserved", C.c_int), ("d1", C.c_double), ("d2", C.c_double), ("d_mean", C.c_double)]
 
 
+class vk_aug_params(C.Structure):
+    _fields_ = [("d4", C.c_int), ("rotate", C.c_int), ("cos_a", C.c_float), ("sin_a", C.c_float), ("photo", C.c_int),
+                ("alpha", C.c_float), ("beta", C.c_float), ("blur_ksize", C.c_int), ("noise_scale", C.c_float),
+                ("noise_seed", C.c_uint32)]
+
+
 class vk_unet_config(C.Structure):
     _fields_ = [("N", C.c_int), ("size", C.c_int), ("dtype", C.c_int), ("training", C.c_int)]
 
@@ -87,6 +93,9 @@ SIGNATURES = {
     "vk_letterbox_postprocess_prob": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
     "vk_geom_workspace_bytes": (i64, [P(vk_geom_desc), ci]),
     "vk_geom_minarearect": (ci, [P(vk_geom_desc), ci, vp, vp, vp, vp, vp, sz, vp]),
+    "vk_letterbox_u8": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
+    "vk_letterbox_mask_u8": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
+    "vk_augment_batch": (ci, [ci, ci, ci, vp, vp, vp, P(vk_aug_params), vp, vp, vp, vp]),
     "vk_input_transform": (ci, [ci, ci, ci, ci, vp, vp, vp]),
     "vk_bn_finalize": (ci, [ci, ci, vp, cd, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
     "vk_bn_relu_maxpool": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
