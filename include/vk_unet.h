@@ -149,11 +149,13 @@ int vk_stem_fwd(vk_dtype dtype, int N, int H, int W, const void* x4, const void*
                 void* stream);
 
 /* dw[K][R][S][C] (fp32, +=; caller zeroes once per step) = sum_pixels dz[n][p][q][k] * V[n][p*stride-pad+r][..][c].
- * workspace (optional, VK_WGRAD_WORKSPACE_BYTES is always enough): when given, the 3x3 stride-1 layers write
- * per-split partial results there and add them up in a fixed order (reproducible); otherwise fp32 atomics. */
+ * workspace (optional, 16-byte aligned, VK_WGRAD_WORKSPACE_BYTES is always enough; dw 16-byte aligned): when given, every
+ * kernel (3x3 stride-1 tile kernel, tap-by-tap kernel for stride 2 / 1x1, stem) writes per-split partial results there and
+ * a second launch adds them up in a fixed order (bit-reproducible gradients); otherwise fp32 atomics. */
 #define VK_WGRAD_WORKSPACE_BYTES (64u << 20)
 int vk_conv_wgrad(const vk_conv_desc* d, const void* dz, float* dw, void* workspace, size_t workspace_bytes, void* stream);
-int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const void* dz, float* dw_krsc3, void* stream);
+int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const void* dz, float* dw_krsc3, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The steps either side of model(x) in the inference wrappers, one fused pass each.
@@ -290,11 +292,14 @@ int vk_upsample2x_bwd(vk_dtype dtype, int N, int H, int W, int C, const void* d_
 /* Segmentation head: 3x3 pad-1 conv C=16 -> 1 with bias on the activated decoder output; fp32 logits. */
 int vk_head_fwd(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* bias,
                 float* logits, void* stream);
+/* workspace (optional, VK_HEAD_WORKSPACE_BYTES is always enough): per-workgroup partial weight gradients that a second launch
+ * adds in workgroup order -> dw / dbias are bit-reproducible; NULL: fp32 atomics */
+#define VK_HEAD_WORKSPACE_BYTES (1024u * 148u * 4u)
 int vk_head_bwd(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* dlogits,
-                void* dy, float* dw9x16, float* dbias, void* stream);
+                void* dy, float* dw9x16, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 /* same, with the BatchNorm+ReLU backward reduce of the head's input layer fused into the dy kernel (see vk_bnr) */
 int vk_head_bwd_fused(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* dlogits,
-                      void* dy, float* dw9x16, float* dbias, const vk_bnr* bnr, void* stream);
+                      void* dy, float* dw9x16, float* dbias, const vk_bnr* bnr, void* workspace, size_t workspace_bytes, void* stream);
 
 /* loss = mean BCE-with-logits + binary Dice (smp defaults: batch-global, smooth 0, eps 1e-7).
  * sums: double[8] scratch (zeroed by the call).  loss_out[0] = w_bce*bce + w_dice*dice, [1] = bce, [2] = dice.

@@ -442,18 +442,18 @@ WGRAD_CASES = [
 WS_ = None      # wgrad workspace of the current test (None => atomics epilogue)
 
 
-@pytest.fixture(params=["tap", "halo", "halo_slab"])
+@pytest.fixture(params=["tap", "tap_slab", "halo", "halo_slab"])
 def wgrad_path(request, monkeypatch):
     """Run every weight-gradient case through both kernels: the tap-by-tap one and (forced onto these small
     shapes) the LDS-staged halo one; shapes the halo kernel does not cover fall back by themselves."""
-    if request.param == "tap":
+    if request.param.startswith("tap"):
         monkeypatch.setenv("VK_NO_WGRAD_HALO", "1")
     else:
         monkeypatch.delenv("VK_NO_WGRAD_HALO", raising=False)
         monkeypatch.setenv("VK_WH_MINBLOCKS", "1")
         monkeypatch.setenv("VK_WH_MAXCOMBO", "1000")
     global WS_
-    WS_ = torch.empty(64 << 20, dtype=torch.uint8, device=dev()) if request.param == "halo_slab" else None
+    WS_ = torch.empty(64 << 20, dtype=torch.uint8, device=dev()) if request.param.endswith("_slab") else None
     yield request.param
     WS_ = None
 
@@ -516,11 +516,17 @@ def test_stem_wgrad(dtn, S):
     x4 = torch.zeros((N, S, S, 4), dtype=dt, device=dev())
     x4[..., :3] = D(x.permute(0, 2, 3, 1).to(dt))
     dzd = to_nhwc(dz, dt)
-    dw = torch.zeros(64, 7, 7, 3, dtype=torch.float32, device=dev())
-    vk._lib.check(vk.lib().vk_stem_wgrad(L_.dtype_code(dt), N, S, S, x4.data_ptr(), dzd.data_ptr(), dw.data_ptr(), st()))
-    torch.cuda.synchronize()
-    err = (dw.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
-    assert err <= (1e-4 if dt == torch.float32 else 2e-3) * ref.abs().max().item(), err
+    ws = torch.empty(16 << 20, dtype=torch.uint8, device=dev())
+    outs = []
+    for wsp in (None, ws, ws):            # fp32 atomics; reproducible slab mode, twice
+        dw = torch.zeros(64, 7, 7, 3, dtype=torch.float32, device=dev())
+        vk._lib.check(vk.lib().vk_stem_wgrad(L_.dtype_code(dt), N, S, S, x4.data_ptr(), dzd.data_ptr(), dw.data_ptr(),
+                                             wsp.data_ptr() if wsp is not None else None, wsp.numel() if wsp is not None else 0, st()))
+        torch.cuda.synchronize()
+        err = (dw.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+        assert err <= (1e-4 if dt == torch.float32 else 2e-3) * ref.abs().max().item(), err
+        outs.append(dw)
+    assert torch.equal(outs[1], outs[2])     # fixed summation order
 
 
 # ------------------------------------------------------------------------------------------------ BN / pool / tails
@@ -713,14 +719,21 @@ def test_head_fwd_bwd(dtn):
     torch.cuda.synchronize()
     assert (logits.cpu() - ref.detach().float()).abs().max().item() <= 1e-4 * ref.abs().max().item()
     dy = torch.empty((N, H, H, 16), dtype=dt, device=dev())
-    dw = torch.zeros(3, 3, 16, device=dev())
-    db = torch.zeros(1, device=dev())
-    vk._lib.check(vk.lib().vk_head_bwd(L_.dtype_code(dt), N, H, H, C.byref(src), w9.data_ptr(), D(dl).data_ptr(), dy.data_ptr(),
-                                       dw.data_ptr(), db.data_ptr(), st()))
-    torch.cuda.synchronize()
-    assert (from_nhwc(dy) - a.grad.float()).abs().max().item() <= tol(dt, a.grad.float())
-    assert (dw.cpu().permute(2, 0, 1) - wv.grad[0].float()).abs().max().item() <= 1e-3 * wv.grad.abs().max().item()
-    assert abs(db.item() - bv.grad.item()) <= 1e-3 * abs(bv.grad.item()) + 1e-4
+    ws = torch.empty(1024 * 148 * 4, dtype=torch.uint8, device=dev())
+    dld = D(dl)
+    outs = []
+    for wsp in (None, ws, ws):            # fp32 atomics; reproducible mode (per-workgroup partials + ordered reduce), twice
+        dw = torch.zeros(3, 3, 16, device=dev())
+        db = torch.zeros(1, device=dev())
+        vk._lib.check(vk.lib().vk_head_bwd(L_.dtype_code(dt), N, H, H, C.byref(src), w9.data_ptr(), dld.data_ptr(), dy.data_ptr(),
+                                           dw.data_ptr(), db.data_ptr(), wsp.data_ptr() if wsp is not None else None,
+                                           wsp.numel() if wsp is not None else 0, st()))
+        torch.cuda.synchronize()
+        assert (from_nhwc(dy) - a.grad.float()).abs().max().item() <= tol(dt, a.grad.float())
+        assert (dw.cpu().permute(2, 0, 1) - wv.grad[0].float()).abs().max().item() <= 1e-3 * wv.grad.abs().max().item()
+        assert abs(db.item() - bv.grad.item()) <= 1e-3 * abs(bv.grad.item()) + 1e-4
+        outs.append((dw, db))
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
 
 
 @pytest.mark.parametrize("wb,wd", [(1.0, 1.0), (0.0, 1.0), (1.0, 0.0)])

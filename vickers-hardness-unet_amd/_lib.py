@@ -80,14 +80,14 @@ SIGNATURES = {
     "vk_conv_fwd": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp, vp]),
     "vk_conv_dgrad_pool2": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp]),
     "vk_conv_dgrad_fused": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, P(vk_bnr), vp]),
-    "vk_head_bwd_fused": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp, vp, P(vk_bnr), vp]),
+    "vk_head_bwd_fused": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp, vp, P(vk_bnr), vp, sz, vp]),
     "vk_halo_pack": (ci, [ci, ci, ci, vp, vp, vp]),
     "vk_conv_uses_halo_pack": (ci, [P(vk_conv_desc)]),
     "vk_conv_fwd_packed": (ci, [P(vk_conv_desc), vp, vp, vp, ci, ci, vp, vp]),
     "vk_conv_fwd_splitk": (ci, [P(vk_conv_desc), vp, vp, vp, sz, vp]),
     "vk_stem_fwd": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     "vk_conv_wgrad": (ci, [P(vk_conv_desc), vp, vp, vp, sz, vp]),
-    "vk_stem_wgrad": (ci, [ci, ci, ci, ci, vp, vp, vp, vp]),
+    "vk_stem_wgrad": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]),
     "vk_letterbox_preprocess": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
     "vk_letterbox_postprocess_mask": (ci, [P(vk_letterbox_desc), vp, cf, vp, vp]),
     "vk_letterbox_postprocess_prob": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
@@ -108,7 +108,7 @@ SIGNATURES = {
     "vk_bn_bwd_apply_fused": (ci, [ci, sz, ci, vp, vp, ci, vp, vp, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
     "vk_upsample2x_bwd": (ci, [ci, ci, ci, ci, ci, vp, vp, ci, vp]),
     "vk_head_fwd": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp]),
-    "vk_head_bwd": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp, vp, vp]),
+    "vk_head_bwd": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp, vp, vp, sz, vp]),
     "vk_bce_dice_loss": (ci, [sz, vp, vp, vp, vp, vp, cf, cf, cf, vp]),
     "vk_adamw_step": (ci, [sz, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, cf, vp, vp, ci, vp]),
     "vk_amp_check_inf": (ci, [sz, vp, vp, vp]),

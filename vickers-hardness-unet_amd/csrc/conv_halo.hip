@@ -48,6 +48,7 @@ struct HaloParams {
   // fused BatchNorm+ReLU backward reduce on the first output part: g = y * [z*scale+shift > 0] is stored instead of y and
   // sum(g), sum(g*z) go to bnr_sums [VK_STATS_REPLICAS][2][ld0]
   unsigned long long* stamps;   // diagnostic builds (-DVK_STAMP) only
+  int kyn;                      // > 0: 1-D grid, the kyn channel tiles of one pixel tile are neighbours ON ONE XCD (see conv3x3_col_kernel)
   int ksplit;                   // > 1: blockIdx.z owns a slice of the channel chunks and writes an fp32 partial tile into `slab`
   size_t slab_bytes;
   float* slab;                  //      [ksplit][N*H*W][K]; k_splitk_reduce adds the slices up in a fixed order (small grids: batch-1 inference)
@@ -564,15 +565,25 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   int bt = blockIdx.x;
+  int ky = blockIdx.y;
   // workgroups go round-robin over the 8 XCDs: give every XCD (its own L2) a contiguous run of tiles so that horizontally
   // adjacent tiles share their halo columns in one L2 (kernel level +1-2 % on the HBM-bound layers, null on the step)
-  if ((gridDim.x & 7) == 0) bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);
+  if (p.kyn > 0) {
+    // K > BN: the channel tiles of ONE pixel tile read the same halo.  1-D grid, id = xcd + 8 * (ky + kyn * t): they are
+    // consecutive workgroups of one XCD, so the second one finds the halo in that XCD's L2 instead of re-reading HBM
+    // (measured before: 1.34x the algorithmic traffic on the K = 256 layers).  Speed only: any placement gives the same result.
+    const int j = bt >> 3;
+    ky = j % p.kyn;
+    bt = (bt & 7) * (int)((gridDim.x / p.kyn) >> 3) + j / p.kyn;
+  } else if ((gridDim.x & 7) == 0) {
+    bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);
+  }
   const int tx = bt % p.tiles_x;
   bt /= p.tiles_x;
   const int ty = bt % p.tiles_y;
   const int n = bt / p.tiles_y;
   const int y0 = ty * TH, x0 = tx * 16;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = ky * BN;
 
   const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.s0.ptr, p.s0.bytes);
   const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.s1.ptr ? p.s1.ptr : p.s0.ptr, p.s1.ptr ? p.s1.bytes : 0u);
@@ -1001,6 +1012,12 @@ static int launch_col(HaloParams p, hipStream_t st) {
   }
   p.ksplit = ks;
   grid.z = (unsigned)ks;
+  p.kyn = 0;
+  if (ks == 1 && grid.y > 1 && (grid.x & 7) == 0 && !getenv("VK_COL_NO_KYFAST")) {
+    p.kyn = (int)grid.y;
+    grid.x *= grid.y;
+    grid.y = 1;
+  }
   static bool attr_done = false;
   if (!attr_done && Cfg::SMEM > 64 * 1024) {
     VK_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_col_kernel<T, TH, BN, WGM, WGN, ADB, MINW>,
@@ -1049,8 +1066,12 @@ static int col_select(const HaloParams& p, hipStream_t st) {
     return launch_col<T, 16, 128, 4, 2, true, 2>(p, st);                    // 8 waves, 4 rows x 64 channels per wave
   }
   if (p.K >= 64) return launch_col<T, 16, 64, 4, 1, false, 2>(p, st);
-  if (p.K >= 32) return launch_col<T, 16, 32, 4, 1, false, 2>(p, st);
-  return launch_col<T, 16, 16, 4, 1, false, 2>(p, st);
+  // small channel counts on the large decoder maps (HBM / latency-bound: a tile is a prologue, a handful of MFMAs and an epilogue):
+  // 32 x 16 pixel tiles halve the number of those fixed costs per byte (VK_COL_TALL=0 restores the 16 x 16 tile for A/B runs)
+  static const bool tall = !(getenv("VK_COL_TALL") && atoi(getenv("VK_COL_TALL")) == 0);
+  const bool big_map = (long)p.H * p.W >= 128 * 128 && p.H % 32 == 0;
+  if (p.K >= 32) return (tall && big_map) ? launch_col<T, 32, 32, 4, 1, false, 2>(p, st) : launch_col<T, 16, 32, 4, 1, false, 2>(p, st);
+  return (tall && big_map) ? launch_col<T, 32, 16, 4, 1, false, 2>(p, st) : launch_col<T, 16, 16, 4, 1, false, 2>(p, st);
 }
 
 template <typename T>
@@ -1125,6 +1146,7 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, 
   p.accumulate = accumulate;
   p.pool2 = pool2;
   p.ksplit = 1;
+  p.kyn = 0;
   p.slab = (reinterpret_cast<uintptr_t>(workspace) & 15) ? nullptr : (float*)workspace;      // 16-byte stores into the slab
   p.slab_bytes = p.slab ? workspace_bytes : 0;
   p.stamps = nullptr;

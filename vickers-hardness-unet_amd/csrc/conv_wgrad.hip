@@ -8,7 +8,9 @@
 // upsample / concat applied to V on the way) and the transposition happens in the LDS read:
 //   16-bit : ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, two reads per fragment)
 //   fp32   : ds_read_b32, lane = (channel, pixel-in-group) — already the 16x16x4 operand layout.
-// Split-K over pixel ranges (grid.z) with fp32 atomics into the flat gradient buffer.
+// Split-K over pixel ranges (grid.z): every split stores its partial tile into a slab of the caller's workspace and
+// k_wgrad_slab_reduce (wgrad_halo.hip) adds the splits in a fixed order -> bit-reproducible gradients (fp32 atomics into
+// the flat gradient buffer only when no workspace is given).
 // Two wave layouts: big tiles split the output tile over the 4 waves; small-channel layers
 // (K or C <= 32: decoder blocks 3/4, stem) give every wave the whole tile on its own 32-pixel slice.
 #include <stdlib.h>
@@ -32,6 +34,7 @@ struct WgradParams {
   const void* dz;
   uint32_t dz_bytes;
   float* dw;
+  float* slab;            // [splits][K * RS * C] partial results (nullptr: fp32 atomics into dw)
   int N, H, W, Ho, Wo, K, R, S, slog, pad;
   int C, M, RS, mps, ctiles, stem;
   FastDiv div_hw, div_w, div_ct, div_s;
@@ -255,7 +258,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: fp32 atomics into dW[k][tap][c] (stem: [k][r][s][3], padding columns dropped) ----
+  // ---- epilogue: dW[k][tap][c] (stem: [k][r][s][3], padding columns dropped): this split's slab, or fp32 atomics ----
+  // (WSPLIT layouts give every wave the whole tile on its own pixel slice: their four partial tiles are added through LDS first)
+  float* const out = p.slab ? p.slab + (size_t)blockIdx.z * ((size_t)p.K * (p.stem ? 147 : p.RS * p.C)) : p.dw;
+  if (WSPLIT && p.slab) {
+    float* red = reinterpret_cast<float*>(smem);           // [wave][TK][TCc][64 lanes][4]: at most 4 * 4 * 4 * 256 * 4 B = 64 KB <= 2 * STAGE
+    static_assert(4 * TK * TCc * 1024 <= Cfg::SMEM || !WSPLIT, "wave-partial tiles must fit the staging buffers");
+#pragma unroll
+    for (int a = 0; a < TK; ++a)
+#pragma unroll
+      for (int b = 0; b < TCc; ++b) *reinterpret_cast<f32x4_t*>(red + (((wave * TK + a) * TCc + b) * 64 + lane) * 4) = acc[a][b];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int a = 0; a < TK; ++a)
+#pragma unroll
+        for (int b = 0; b < TCc; ++b) {
+          f32x4_t t = acc[a][b];
+#pragma unroll
+          for (int w = 1; w < 4; ++w) t = t + *reinterpret_cast<const f32x4_t*>(red + (((w * TK + a) * TCc + b) * 64 + lane) * 4);
+          acc[a][b] = t;
+        }
+    } else {
+      return;
+    }
+  }
 #pragma unroll
   for (int a = 0; a < TK; ++a)
 #pragma unroll
@@ -265,19 +292,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       for (int e = 0; e < 4; ++e) {
         const int k = k0 + wk0 + a * 16 + (lane >> 4) * 4 + e;
         if (k >= p.K) continue;
+        float* dst = nullptr;
         if (!p.stem) {
-          if (cc < p.C) atomicAdd(p.dw + ((size_t)k * p.RS + tap) * p.C + cc, acc[a][b][e]);
+          if (cc < p.C) dst = out + ((size_t)k * p.RS + tap) * p.C + cc;
         } else {
           const int sx = cc >> 2, ci = cc & 3;
-          if (sx < 7 && ci < 3) atomicAdd(p.dw + (((size_t)k * 7 + tap) * 7 + sx) * 3 + ci, acc[a][b][e]);
+          if (sx < 7 && ci < 3) dst = out + (((size_t)k * 7 + tap) * 7 + sx) * 3 + ci;
         }
+        if (!dst) continue;
+        if (p.slab) *dst = acc[a][b][e];
+        else atomicAdd(dst, acc[a][b][e]);
       }
     }
 }
 
+void launch_slab_reduce(size_t n4, int splits, const float* slab, float* dw, hipStream_t st);     // wgrad_halo.hip
+
 // ------------------------------------------------------------------------------------------------ host
 template <typename T, int BMW, int BNW, bool WSPLIT>
-static int launch_w(WgradParams p, hipStream_t st) {
+static int launch_w(WgradParams p, void* workspace, size_t workspace_bytes, hipStream_t st) {
   using Cfg = WgradCfg<T, BMW, BNW, WSPLIT>;
   p.ctiles = (p.C + BNW - 1) / BNW;
   p.div_ct = vkh::make_fastdiv((uint32_t)p.ctiles);
@@ -288,9 +321,18 @@ static int launch_w(WgradParams p, hipStream_t st) {
   int splits = (1024 + out_tiles - 1) / out_tiles;
   if (splits > chunks / 8) splits = chunks / 8;
   if (splits < 1) splits = 1;
+  // reproducible mode: the splits' partial results go to a slab in the workspace ([splits][K * RS * C] floats) and are added in split order
+  const size_t out_elems = (size_t)p.K * (p.stem ? 147 : (size_t)p.RS * p.C);
+  const bool use_slab = workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && out_elems % 4 == 0 && workspace_bytes >= out_elems * 4 &&
+                        (reinterpret_cast<uintptr_t>(p.dw) & 15) == 0 && !getenv("VK_WGRAD_ATOMICS");
+  if (use_slab) {
+    const size_t cap = workspace_bytes / (out_elems * 4);
+    if ((size_t)splits > cap) splits = (int)cap;
+  }
   int cps = (chunks + splits - 1) / splits;
   p.mps = cps * Cfg::PX;
   splits = (p.M + p.mps - 1) / p.mps;
+  p.slab = use_slab ? (float*)workspace : nullptr;
   dim3 grid(ktiles, p.ctiles * p.RS, splits);
   static bool attr_done = false;
   if (!attr_done && Cfg::SMEM > 64 * 1024) {
@@ -309,27 +351,28 @@ static int launch_w(WgradParams p, hipStream_t st) {
     vkh::ProfScope ps(dtag.c_str(), st, 2.0 * (double)p.M * p.K * rsc, bytes);
     hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW, WSPLIT>), grid, dim3(256), Cfg::SMEM, st, p);
   }
+  if (use_slab) launch_slab_reduce(out_elems / 4, splits, p.slab, p.dw, st);
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }
 
 template <typename T>
-static int launch_w_shape(const WgradParams& p, int cmin, hipStream_t st) {
+static int launch_w_shape(const WgradParams& p, int cmin, void* ws, size_t wsb, hipStream_t st) {
   // cmin = smallest per-source channel count (a c-tile must not straddle the concat boundary)
-  if (p.K >= 128 && cmin % 128 == 0) return launch_w<T, 128, 128, false>(p, st);
-  if (p.K >= 64 && cmin % 64 == 0) return launch_w<T, 64, 64, false>(p, st);
-  if (p.K >= 64 && cmin % 32 == 0) return launch_w<T, 64, 32, true>(p, st);
-  if (p.K >= 32 && cmin % 64 == 0) return launch_w<T, 32, 64, true>(p, st);
-  if (p.K >= 32 && cmin % 32 == 0) return launch_w<T, 32, 32, true>(p, st);
-  if (cmin % 32 == 0) return launch_w<T, 16, 32, true>(p, st);
-  return launch_w<T, 16, 16, true>(p, st);
+  if (p.K >= 128 && cmin % 128 == 0) return launch_w<T, 128, 128, false>(p, ws, wsb, st);
+  if (p.K >= 64 && cmin % 64 == 0) return launch_w<T, 64, 64, false>(p, ws, wsb, st);
+  if (p.K >= 64 && cmin % 32 == 0) return launch_w<T, 64, 32, true>(p, ws, wsb, st);
+  if (p.K >= 32 && cmin % 64 == 0) return launch_w<T, 32, 64, true>(p, ws, wsb, st);
+  if (p.K >= 32 && cmin % 32 == 0) return launch_w<T, 32, 32, true>(p, ws, wsb, st);
+  if (cmin % 32 == 0) return launch_w<T, 16, 32, true>(p, ws, wsb, st);
+  return launch_w<T, 16, 16, true>(p, ws, wsb, st);
 }
 
-static int dispatch_w(vk_dtype dt, const WgradParams& p, int cmin, hipStream_t st) {
+static int dispatch_w(vk_dtype dt, const WgradParams& p, int cmin, void* ws, size_t wsb, hipStream_t st) {
   switch (dt) {
-    case VK_F32: return launch_w_shape<float>(p, cmin, st);
-    case VK_BF16: return launch_w_shape<bf16_t>(p, cmin, st);
-    case VK_F16: return launch_w_shape<f16_t>(p, cmin, st);
+    case VK_F32: return launch_w_shape<float>(p, cmin, ws, wsb, st);
+    case VK_BF16: return launch_w_shape<bf16_t>(p, cmin, ws, wsb, st);
+    case VK_F16: return launch_w_shape<f16_t>(p, cmin, ws, wsb, st);
   }
   vkh::set_error("bad dtype %d", (int)dt);
   return VK_ERR_ARG;
@@ -364,6 +407,7 @@ int conv_wgrad_impl(const vk_conv_desc* d, const void* dz, float* dw, void* work
   p.dz = dz;
   p.dz_bytes = (uint32_t)dz_bytes;
   p.dw = dw;
+  p.slab = nullptr;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.K = d->K; p.R = d->R; p.S = d->S;
   p.slog = d->stride == 2 ? 1 : 0;
   p.pad = d->pad;
@@ -382,7 +426,7 @@ int conv_wgrad_impl(const vk_conv_desc* d, const void* dz, float* dw, void* work
     while (g > 16 && (d->src0.C % g || d->src1.C % g)) g >>= 1;
     cmin = g;
   }
-  return dispatch_w(d->dtype, p, cmin, st);
+  return dispatch_w(d->dtype, p, cmin, workspace, workspace_bytes, st);
 }
 
 // ---- stem (7x7 stride 2, 3->64) weight gradient for the 16-bit types: one workgroup stages a 4 x 32 output-pixel tile of dz
@@ -397,6 +441,7 @@ struct StemWgParams {
   const void* x4;
   const void* dz;
   float* dw;
+  float* slab;            // [gridDim.x][64 * 147] per-workgroup partial results (nullptr: fp32 atomics into dw)
   uint32_t x_bytes, dz_bytes;
   int N, H, W, Ho, Wo, tiles_x, tiles_y, ntiles;
 };
@@ -509,13 +554,16 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemWgParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int k = wave * 16 + (lane >> 4) * 4 + e;
-          atomicAdd(p.dw + (((size_t)k * 7 + r) * 7 + sx) * 3 + ci, acc[r][h][e]);
+          const size_t off = (((size_t)k * 7 + r) * 7 + sx) * 3 + ci;
+          if (p.slab) p.slab[(size_t)blockIdx.x * (64 * 147) + off] = acc[r][h][e];       // every workgroup writes all 9,408 elements
+          else atomicAdd(p.dw + off, acc[r][h][e]);
         }
       }
     }
 }
 
-int stem_wgrad_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void* dz, float* dw, hipStream_t st) {
+int stem_wgrad_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
+                    hipStream_t st) {
   VK_CHECK_ARG(x4 && dz && dw, "vk_stem_wgrad: null argument");
   const int eb = dt == VK_F32 ? 4 : 2;
   if (dt != VK_F32 && !getenv("VK_STEM_WGRAD_TAPS") && (size_t)N * (H / 2) * (W / 2) * 64 * 2 < (1ull << 31)) {
@@ -526,11 +574,20 @@ int stem_wgrad_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void
     q.dz_bytes = (uint32_t)((size_t)N * q.Ho * q.Wo * 64 * 2);
     q.tiles_x = (q.Wo + 31) / 32; q.tiles_y = (q.Ho + 3) / 4;
     q.ntiles = N * q.tiles_y * q.tiles_x;
-    const int nb = q.ntiles < 512 ? q.ntiles : 512;
+    int nb = q.ntiles < 512 ? q.ntiles : 512;
+    const size_t out_elems = 64 * 147;
+    q.slab = nullptr;
+    if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 &&
+        workspace_bytes >= out_elems * 4 && !getenv("VK_WGRAD_ATOMICS")) {
+      const size_t cap = workspace_bytes / (out_elems * 4);
+      if ((size_t)nb > cap) nb = (int)cap;
+      q.slab = (float*)workspace;
+    }
     static const std::string tag = "wgrad_stem_16b";
     vkh::ProfScope ps(tag.c_str(), st, 2.0 * (double)N * q.Ho * q.Wo * 64.0 * 147.0, ((double)N * H * W * 4 + (double)N * q.Ho * q.Wo * 64) * 2.0 + 64.0 * 147 * 4);
     if (dt == VK_BF16) hipLaunchKernelGGL(k_stem_wgrad<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, q);
     else hipLaunchKernelGGL(k_stem_wgrad<f16_t>, dim3((unsigned)nb), dim3(256), 0, st, q);
+    if (q.slab) launch_slab_reduce(out_elems / 4, nb, q.slab, dw, st);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
   }
@@ -540,6 +597,7 @@ int stem_wgrad_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void
   p.dz = dz;
   p.dz_bytes = (uint32_t)((size_t)N * (H / 2) * (W / 2) * 64 * eb);
   p.dw = dw;
+  p.slab = nullptr;
   p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2; p.K = 64; p.R = 7; p.S = 1;
   p.slog = 1; p.pad = 3;
   p.C = 32;
@@ -550,9 +608,9 @@ int stem_wgrad_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void
   p.div_w = vkh::make_fastdiv((uint32_t)p.Wo);
   p.div_s = vkh::make_fastdiv(1);
   switch (dt) {
-    case VK_F32: return launch_w<float, 64, 32, true>(p, st);
-    case VK_BF16: return launch_w<bf16_t, 64, 32, true>(p, st);
-    case VK_F16: return launch_w<f16_t, 64, 32, true>(p, st);
+    case VK_F32: return launch_w<float, 64, 32, true>(p, workspace, workspace_bytes, st);
+    case VK_BF16: return launch_w<bf16_t, 64, 32, true>(p, workspace, workspace_bytes, st);
+    case VK_F16: return launch_w<f16_t, 64, 32, true>(p, workspace, workspace_bytes, st);
   }
   return VK_ERR_ARG;
 }
@@ -562,7 +620,7 @@ int stem_wgrad_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void
 extern "C" int vk_conv_wgrad(const vk_conv_desc* d, const void* dz, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
   return vk::conv_wgrad_impl(d, dz, dw, workspace, workspace_bytes, (hipStream_t)stream);
 }
-extern "C" int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const void* dz, float* dw_krsc3,
-                             void* stream) {
-  return vk::stem_wgrad_impl(dtype, N, H, W, x4, dz, dw_krsc3, (hipStream_t)stream);
+extern "C" int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const void* dz, float* dw_krsc3, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  return vk::stem_wgrad_impl(dtype, N, H, W, x4, dz, dw_krsc3, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -1098,7 +1098,7 @@ int backward_stem(vk_unet* h, hipStream_t st) {
   }
   hipStream_t ws;
   RET_IF(wgrad_stream(h, st, &ws));
-  return vk_stem_wgrad(h->cfg.dtype, N, S, S, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, ws);
+  return vk_stem_wgrad(h->cfg.dtype, N, S, S, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, ws);
 }
 
 int backward_stage(vk_unet* h, const float* dlogits, int stage, hipStream_t st) {
@@ -1113,9 +1113,9 @@ int backward_stage(vk_unet* h, const float* dlogits, int stage, hipStream_t st) 
         const bool fuse = !getenv("VK_NO_BNR_FUSION");
         const float* dl = dlogits ? dlogits : (const float*)(h->ws + h->off_dlogits);
         if (fuse) RET_IF(vk_head_bwd_fused(h->cfg.dtype, N, S, S, &hs, h->params + h->head_w_off, dl, last.g, h->grads + h->head_w_off,
-                                           h->grads + h->head_b_off, &r, st));
+                                           h->grads + h->head_b_off, &r, h->ws + h->off_wslab, VK_HEAD_WORKSPACE_BYTES, st));
         else RET_IF(vk_head_bwd(h->cfg.dtype, N, S, S, &hs, h->params + h->head_w_off, dl, last.g, h->grads + h->head_w_off,
-                                h->grads + h->head_b_off, st));
+                                h->grads + h->head_b_off, h->ws + h->off_wslab, VK_HEAD_WORKSPACE_BYTES, st));
         h->g_prereduced[h->decs[4].conv2] = fuse ? 1 : 0;
       }
       RET_IF(backward_decoder(h, 4, st));

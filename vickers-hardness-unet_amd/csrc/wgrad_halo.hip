@@ -433,6 +433,12 @@ static int launch_wh(WhParams p, size_t slab_bytes, hipStream_t st) {
   return VK_OK;
 }
 
+// shared with conv_wgrad.hip (tap-by-tap and stem kernels in reproducible mode)
+void launch_slab_reduce(size_t n4, int splits, const float* slab, float* dw, hipStream_t st) {
+  vkh::ProfScope ps("wgrad_slab_reduce", st, 0.0, (double)(splits + 2) * n4 * 16.0);
+  hipLaunchKernelGGL(k_wgrad_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, n4, splits, slab, dw);
+}
+
 template <typename T>
 static int wh_select(const WhParams& p, int cgran, size_t slab_bytes, hipStream_t st) {
   // cgran: channel granularity that keeps a c-tile inside one concat source
