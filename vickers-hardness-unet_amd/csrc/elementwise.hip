@@ -896,6 +896,357 @@ __global__ __launch_bounds__(256) void k_head_wgrad_reduce(int nb, const float* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K10: BCE-with-logits (mean) + binary Dice (batch-global, smooth 0, eps 1e-7)
+__global__ __launch_bounds__(256) void k_loss_reduce(size_t count, const float* __restrict__ x, const float* __restrict__ y,
+                                                     double* sums, int vec_ok) {
+  float bce = 0.f, py = 0.f, ps = 0.f, ys = 0.f;
+  auto term = [&](float xv, float yv) {
+    bce += fmaxf(xv, 0.f) - xv * yv + log1pf(expf(-fabsf(xv)));
+    const float p = 1.f / (1.f + expf(-xv));
+    py += p * yv;
+    ps += p;
+    ys += yv;
+  };
+  const size_t gtid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = vec_ok ? count / 4 : 0;          // 16-byte loads when both tensors are 16-byte aligned
+  for (size_t i = gtid; i < n4; i += stride) {
+    const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(x + 4 * i), yv = *reinterpret_cast<const f32x4_t*>(y + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) term(xv[e], yv[e]);
+  }
+  for (size_t i = n4 * 4 + gtid; i < count; i += stride) term(x[i], y[i]);
+  __shared__ double red[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double a = wave_sum_d((double)bce), b = wave_sum_d((double)py), c = wave_sum_d((double)ps), d = wave_sum_d((double)ys);
+  if (lane == 0) { red[wave][0] = a; red[wave][1] = b; red[wave][2] = c; red[wave][3] = d; }
+  __syncthreads();
+  if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// sums[0..3] = {bce, p*y, p, y}; writes loss_out[0..2] and the two Dice gradient coefficients to sums[4..5]
+__global__ void k_loss_finalize(double count, double* sums, float* loss_out, float w_bce, float w_dice) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double bce = sums[0] / count;
+  const double I = sums[1], card = sums[2] + sums[3], ysum = sums[3];
+  const double eps = 1e-7;
+  const double denom = card > eps ? card : eps;
+  const double mask = ysum > 0.0 ? 1.0 : 0.0;
+  const double dice = (1.0 - 2.0 * I / denom) * mask;
+  loss_out[0] = (float)(w_bce * bce + w_dice * dice);
+  loss_out[1] = (float)bce;
+  loss_out[2] = (float)dice;
+  // d dice / d p_i = -2 (y_i * card - I) / card^2  (clamp inactive whenever mask == 1)
+  sums[4] = card > eps ? -2.0 * w_dice * mask / card : 0.0;            // multiplies y_i
+  sums[5] = card > eps ? 2.0 * w_dice * mask * I / (card * card) : 0.0;  // constant term
+  sums[6] = w_bce / count;
+}
+
+__global__ void k_loss_bwd(size_t count, const float* __restrict__ x, const float* __restrict__ y, const double* __restrict__ sums,
+                           float grad_scale, float* __restrict__ dl) {
+  const float ky = (float)sums[4], k0 = (float)sums[5];
+  const float invc = (float)sums[6];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const float xv = x[i], yv = y[i];
+    const float p = 1.f / (1.f + expf(-xv));
+    const float g = (p - yv) * invc + (ky * yv + k0) * p * (1.f - p);
+    dl[i] = g * grad_scale;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K15: AdamW over the flat fp32 buffers (same arithmetic order as torch/optim/adam.py single-tensor path)
+template <typename LT>
+__global__ void k_adamw(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                        float lr, float beta1, float beta2, float eps, float wd, float step_size, float bc2_sqrt,
+                        float inv_scale, const int* found_inf, LT* lowp) {
+  if (found_inf && *found_inf) return;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * inv_scale;
+    float pi = p[i] * (1.f - lr * wd);
+    float mi = m[i];
+    mi = mi + (gi - mi) * (1.f - beta1);
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - step_size * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (lowp) st1(lowp + i, pi);
+  }
+}
+
+__global__ void k_check_inf(size_t n, const float* __restrict__ g, int* found) {
+  bool bad = false;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    bad |= !isfinite(g[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(found, 1);
+}
+
+// K16, GradScaler form (torch._amp_foreach_non_finite_check_and_unscale_ over the ONE flat gradient buffer):
+// g *= *inv_scale (skipped when the factor is exactly 1: GradScaler's check-only call passes a dummy 1.0), *found_inf = 1.0f if any
+// element is inf / nan.  16-byte accesses; n4 = n / 4 (the flat buffer is padded to a multiple of 64 elements).
+__global__ __launch_bounds__(256) void k_amp_unscale_check(size_t n4, float* __restrict__ g, const float* __restrict__ inv_scale,
+                                                           float* __restrict__ found_inf) {
+  const float inv = inv_scale ? *inv_scale : 1.f;
+  const bool scale = inv != 1.f;
+  bool bad = false;
+  f32x4_t* g4 = reinterpret_cast<f32x4_t*>(g);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4_t v = g4[i];
+    bad |= !(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]));
+    if (scale) {
+      v = v * inv;
+      g4[i] = v;
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.f;     // every writer stores the same value
+}
+
+// One thread: resolves the GradScaler protocol on the device for k_adamw_dev (no host round trip, train.py:443-445).
+//   st[0] = skip flag (found_inf != 0), st[1] = lr / (1 - beta1^t), st[2] = sqrt(1 - beta2^t), st[3] = inv_scale / grad_scale;
+//   the step counter t advances only when the step is taken (torch: optimizer.step() is not called on an overflow).
+__global__ void k_adamw_prepare(int* __restrict__ step_count, const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
+                                float lr, float beta1, float beta2, float inv_scale, float* __restrict__ st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const bool skip = found_inf && *found_inf != 0.f;
+  int t = *step_count;
+  if (!skip) {
+    t += 1;
+    *step_count = t;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, (double)(t > 0 ? t : 1));
+  const double bc2 = 1.0 - pow((double)beta2, (double)(t > 0 ? t : 1));
+  st[0] = skip ? 1.f : 0.f;
+  st[1] = (float)((double)lr / bc1);
+  st[2] = (float)sqrt(bc2);
+  st[3] = grad_scale ? (float)((double)inv_scale / (double)*grad_scale) : inv_scale;
+}
+
+template <typename LT>
+__global__ void k_adamw_dev(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            float lr, float beta1, float beta2, float eps, float wd, const float* __restrict__ st, LT* lowp) {
+  if (st[0] != 0.f) return;
+  const float step_size = st[1], bc2_sqrt = st[2], inv_scale = st[3];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * inv_scale;
+    float pi = p[i] * (1.f - lr * wd);
+    float mi = m[i];
+    mi = mi + (gi - mi) * (1.f - beta1);
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - step_size * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (lowp) st1(lowp + i, pi);
+  }
+}
+
+}  // namespace vk
+
+// =================================================================================================
+// C ABI wrappers
+// =================================================================================================
+using namespace vk;
+
+#define DISPATCH_T(dt, CALL)                         \
+  switch (dt) {                                      \
+    case VK_F32: { using T = float; CALL; } break;   \
+    case VK_BF16: { using T = bf16_t; CALL; } break; \
+    case VK_F16: { using T = f16_t; CALL; } break;   \
+    default: vkh::set_error("bad dtype %d", (int)dt); return VK_ERR_ARG; \
+  }
+
+extern "C" int vk_input_transform(vk_dtype dtype, int N, int H, int W, const float* x, void* x4, void* stream) {
+  VK_CHECK_ARG(x && x4 && N > 0 && H > 0 && W > 0, "vk_input_transform: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("input_transform", st, 0.0, (double)N * H * W * (12.0 + 4.0 * (dtype == VK_F32 ? 4.0 : 2.0)));
+  VK_CHECK_ARG(N <= 65535, "vk_input_transform: N too large for the launch grid");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_input_transform<T>, dim3(grid_for((size_t)H * W, 256, 1024), (unsigned)N), dim3(256), 0, st, N, H, W, x, (T*)x4));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_bn_finalize(int C, int train, const double* stats, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float eps, float momentum, float* scale, float* shift,
+                              float* save_mean, float* save_invstd, void* stream) {
+  VK_CHECK_ARG(C > 0 && gamma && beta && scale && shift, "vk_bn_finalize: null argument");
+  VK_CHECK_ARG(train ? (stats != nullptr && count > 0) : (running_mean && running_var), "vk_bn_finalize: missing statistics");
+  vkh::ProfScope ps_("bn_finalize", (hipStream_t)stream, 0.0, (double)C * 40.0);
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, C, train, stats, count, gamma, beta,
+                     running_mean, running_var, eps, momentum, scale, shift, save_mean, save_invstd);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_bn_relu_maxpool(vk_dtype dtype, int N, int H, int W, int C, const void* z, const float* scale,
+                                  const float* shift, void* pooled, uint8_t* argmax, void* stream) {
+  VK_CHECK_ARG(z && scale && shift && pooled && argmax, "vk_bn_relu_maxpool: null argument");
+  VK_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "vk_bn_relu_maxpool: H, W even and C %% 8 == 0 required");
+  hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("bn_relu_maxpool", st, 0.0, (double)N * H * W * C * (dtype == VK_F32 ? 4.0 : 2.0) * 1.25 + (double)N * H * W * C / 4.0);
+  VK_CHECK_ARG(N <= 65535 && H / 2 <= 65535, "vk_bn_relu_maxpool: N or H too large for the launch grid");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_relu_maxpool<T>, dim3((unsigned)(((W / 2) * (C / ElemTraits<T>::kVec) + 255) / 256), (unsigned)(H / 2), (unsigned)N),
+                                       dim3(256), 0, st, N, H, W, C, (const T*)z, scale, shift, (T*)pooled, argmax));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_maxpool_bwd(vk_dtype dtype, int N, int H, int W, int C, const void* dpool, const uint8_t* argmax, void* dy,
+                              void* stream) {
+  VK_CHECK_ARG(dpool && argmax && dy && C % 8 == 0, "vk_maxpool_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("maxpool_bwd", st, 0.0, (double)N * H * W * C * (dtype == VK_F32 ? 4.0 : 2.0) * 2.25 + (double)N * H * W * C / 4.0);
+  VK_CHECK_ARG(N <= 65535 && H <= 65535 && H % 2 == 0 && W % 2 == 0, "vk_maxpool_bwd: N or H too large for the launch grid, or odd size");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3((unsigned)((W * (C / ElemTraits<T>::kVec) + 255) / 256), (unsigned)H, (unsigned)N), dim3(256), 0, st,
+                                       N, H, W, C, (const T*)dpool, argmax, (T*)dy));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_maxpool_bwd_bn_reduce(vk_dtype dtype, int N, int H, int W, int C, const void* dpool, const uint8_t* argmax, const void* z,
+                                        const float* scale, const float* shift, void* dy, double* sums, void* stream) {
+  VK_CHECK_ARG(dpool && argmax && z && scale && shift && dy && sums, "vk_maxpool_bwd_bn_reduce: null argument");
+  VK_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "vk_maxpool_bwd_bn_reduce: H, W even and C %% 8 == 0 required");
+  const int cv = C / (dtype == VK_F32 ? 4 : 8);
+  VK_CHECK_ARG(cv <= 256 && 256 % cv == 0, "vk_maxpool_bwd_bn_reduce: C=%d unsupported", C);
+  VK_CHECK_ARG(N <= 65535 && H <= 65535 * vk::PB_ROWS, "vk_maxpool_bwd_bn_reduce: N or H too large for the launch grid");
+  hipStream_t st = (hipStream_t)stream;
+  const double eb = dtype == VK_F32 ? 4.0 : 2.0;
+  vkh::ProfScope ps_("maxpool_bwd_bn_reduce", st, 0.0, (double)N * H * W * C * eb * 3.25 + (double)N * H * W * C / 4.0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_bwd_bn_reduce<T>, dim3((unsigned)((W * cv + 255) / 256), (unsigned)((H + PB_ROWS - 1) / PB_ROWS), (unsigned)N),
+                                       dim3(256), 0, st, N, H, W, C, (const T*)dpool, argmax, (const T*)z, scale, shift, (T*)dy, sums));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_bn_add_relu(vk_dtype dtype, size_t pixels, int C, const void* z, const float* scale, const float* shift,
+                              const void* res, const float* rscale, const float* rshift, void* out, void* stream) {
+  VK_CHECK_ARG(z && scale && shift && res && out && C % 8 == 0, "vk_bn_add_relu: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("bn_add_relu", st, 0.0, (double)pixels * C * (dtype == VK_F32 ? 4.0 : 2.0) * 3.0);
+  VK_CHECK_ARG(C <= 512, "vk_bn_add_relu: C=%d unsupported", C);
+  // four vectors per thread (one unrolled pass) before the grid grows; the grid stays a multiple of C/VE threads
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_add_relu<T>, dim3(grid_for((pixels * (C / ElemTraits<T>::kVec) + 3) / 4)), dim3(256), 0, st, pixels, C,
+                                       (const T*)z, scale, shift, (const T*)res, rscale, rshift, (T*)out));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+template <typename T>
+static int launch_bn_bwd_reduce(size_t pixels, int C, const void* dy, const void* z, int mask_mode, const float* scale,
+                                const float* shift, const void* mask_src, double* sums, hipStream_t st) {
+  const int CV = C / ElemTraits<T>::kVec;
+  const int rows = 256 / CV;
+  // every block ends with 2*C fp64 atomics, so give each at least 16 row passes
+  size_t nb = (pixels + (size_t)rows * 16 - 1) / ((size_t)rows * 16);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  dim3 grid((unsigned)nb), block(256);
+  if (mask_mode == 0) hipLaunchKernelGGL((k_bn_bwd_reduce<T, 0>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, sums);
+  else if (mask_mode == 1) hipLaunchKernelGGL((k_bn_bwd_reduce<T, 1>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, sums);
+  else hipLaunchKernelGGL((k_bn_bwd_reduce<T, 2>), grid, block, 0, st, pixels, C, (const T*)dy, (const T*)z, scale, shift, (const T*)mask_src, sums);
+  return VK_OK;
+}
+
+extern "C" int vk_bn_bwd_reduce(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
+                                const float* scale, const float* shift, const void* mask_src, double* sums, void* stream) {
+  VK_CHECK_ARG(dy && z && sums, "vk_bn_bwd_reduce: null argument");
+  VK_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "vk_bn_bwd_reduce: mask_mode %d", mask_mode);
+  VK_CHECK_ARG(mask_mode != 1 || (scale && shift), "vk_bn_bwd_reduce: mask_mode 1 needs scale/shift");
+  VK_CHECK_ARG(mask_mode != 2 || mask_src, "vk_bn_bwd_reduce: mask_mode 2 needs mask_src");
+  VK_CHECK_ARG(C % 8 == 0 && C <= 512, "vk_bn_bwd_reduce: C=%d unsupported", C);
+  hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("bn_bwd_reduce", st, 0.0, (double)pixels * C * (dtype == VK_F32 ? 4.0 : 2.0) * (mask_mode == 2 ? 3.0 : 2.0));
+  DISPATCH_T(dtype, launch_bn_bwd_reduce<T>(pixels, C, dy, z, mask_mode, scale, shift, mask_src, sums, st));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_bn_bwd_coeffs(int C, const double* sums, double count, const float* gamma, const float* save_mean,
+                                const float* save_invstd, float* dgamma, float* dbeta, float* coef_abc, void* stream) {
+  VK_CHECK_ARG(sums && gamma && save_mean && save_invstd && dgamma && dbeta && coef_abc, "vk_bn_bwd_coeffs: null argument");
+  vkh::ProfScope ps_("bn_bwd_coeffs", (hipStream_t)stream, 0.0, (double)C * 48.0);
+  hipLaunchKernelGGL(k_bn_bwd_coeffs, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, C, sums, count, gamma, save_mean,
+                     save_invstd, dgamma, dbeta, coef_abc);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+struct BnApplyArgs {
+  size_t pixels; int C; const void* dy; const void* z; int mask_mode; const float* scale; const float* shift; const void* mask_src;
+  const float* coef; const double* sums; double count; const float* gamma; const float* mean; const float* invstd; float* dgamma; float* dbeta;
+  void* dz; void* g_out; int g_acc;
+};
+
+template <typename T>
+static int launch_bn_bwd_apply(const BnApplyArgs& a, hipStream_t st) {
+  const int CV = a.C / ElemTraits<T>::kVec;
+  // grid * 256 must be a multiple of CV (<= 128): any block count works; keep enough blocks to fill the chip
+  dim3 grid(grid_for(a.pixels * CV / 2 + 1)), block(256);
+#define VK_APPLY(M) hipLaunchKernelGGL((k_bn_bwd_apply<T, M>), grid, block, 0, st, a.pixels, a.C, (const T*)a.dy, (const T*)a.z, a.scale, a.shift, \
+    (const T*)a.mask_src, a.coef, a.sums, a.count, a.gamma, a.mean, a.invstd, a.dgamma, a.dbeta, (T*)a.dz, (T*)a.g_out, a.g_acc)
+  if (a.mask_mode == 0) VK_APPLY(0);
+  else if (a.mask_mode == 1) VK_APPLY(1);
+  else VK_APPLY(2);
+#undef VK_APPLY
+  return VK_OK;
+}
+
+static int bn_bwd_apply_common(vk_dtype dtype, const BnApplyArgs& a, void* stream) {
+  VK_CHECK_ARG(a.dy && a.z && a.dz && (a.coef || (a.sums && a.gamma && a.mean && a.invstd && a.dgamma && a.dbeta)), "vk_bn_bwd_apply: null argument");
+  VK_CHECK_ARG(a.mask_mode >= 0 && a.mask_mode <= 2, "vk_bn_bwd_apply: mask_mode %d", a.mask_mode);
+  VK_CHECK_ARG(a.mask_mode != 1 || (a.scale && a.shift), "vk_bn_bwd_apply: mask_mode 1 needs scale/shift");
+  VK_CHECK_ARG(a.mask_mode != 2 || a.mask_src, "vk_bn_bwd_apply: mask_mode 2 needs mask_src");
+  VK_CHECK_ARG(a.C <= 512 && a.C % 8 == 0, "vk_bn_bwd_apply: C=%d unsupported", a.C);
+  hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("bn_bwd_apply", st, 0.0, (double)a.pixels * a.C * (dtype == VK_F32 ? 4.0 : 2.0) * ((a.mask_mode == 2 ? 4.0 : 3.0) + (a.g_out ? (a.g_acc ? 2.0 : 1.0) : 0.0)));
+  DISPATCH_T(dtype, launch_bn_bwd_apply<T>(a, st));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_bn_bwd_apply(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
+                               const float* scale, const float* shift, const void* mask_src, const float* coef_abc, void* dz,
+                               void* g_out, int g_accumulate, void* stream) {
+  VK_CHECK_ARG(coef_abc, "vk_bn_bwd_apply: null coefficients");
+  BnApplyArgs a{pixels, C, dy, z, mask_mode, scale, shift, mask_src, coef_abc, nullptr, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, dz, g_out, g_accumulate};
+  return bn_bwd_apply_common(dtype, a, stream);
+}
+
+extern "C" int vk_bn_bwd_apply_fused(vk_dtype dtype, size_t pixels, int C, const void* dy, const void* z, int mask_mode,
+                                     const float* scale, const float* shift, const void* mask_src, const double* sums, double count,
+                                     const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                                     void* dz, void* g_out, int g_accumulate, void* stream) {
+  BnApplyArgs a{pixels, C, dy, z, mask_mode, scale, shift, mask_src, nullptr, sums, count, gamma, save_mean, save_invstd, dgamma, dbeta, dz, g_out, g_accumulate};
+  return bn_bwd_apply_common(dtype, a, stream);
+}
+
+extern "C" int vk_upsample2x_bwd(vk_dtype dtype, int N, int H, int W, int C, const void* d_up, void* d_low, int accumulate,
+                                 void* stream) {
+  VK_CHECK_ARG(d_up && d_low && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "vk_upsample2x_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("upsample2x_bwd", st, 0.0, (double)N * H * W * C * (dtype == VK_F32 ? 4.0 : 2.0) * 1.25);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_upsample2x_bwd<T>, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * (C / ElemTraits<T>::kVec))),
+                                       dim3(256), 0, st, N, H, W, C, (const T*)d_up, (T*)d_low, accumulate));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_head_fwd(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* bias,
+                           float* logits, void* stream) {
+  VK_CHECK_ARG(src && src->ptr && w9x16 && bias && logits, "vk_head_fwd: null argument");
+  VK_CHECK_ARG(src->C == 16 && !src->up, "vk_head_fwd: head input must have 16 channels, no upsample");
+  hipStream_t st = (hipStream_t)stream;
+  vkh::ProfScope ps_("head_fwd", st, 2.0 * 144.0 * N * H * W, (double)N * H * W * (16.0 * (dtype == VK_F32 ? 4.0 : 2.0) + 4.0));
+  const int tx = (W + 15) / 16, ty = (H + 15) / 16;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_fwd<T>, dim3((unsigned)(N * tx * ty)), dim3(256), 0, st, N, H, W, tx, ty, (const T*)src->ptr,
+                                       src->scale, src->shift, src->relu, w9x16, bias, logits));
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
 static int head_bwd_impl(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* dlogits,
                          void* dy, float* dw9x16, float* dbias, const vk_bnr* bnr, void* workspace, size_t workspace_bytes, void* stream);
 
