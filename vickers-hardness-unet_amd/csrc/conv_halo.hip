@@ -1066,12 +1066,10 @@ static int col_select(const HaloParams& p, hipStream_t st) {
     return launch_col<T, 16, 128, 4, 2, true, 2>(p, st);                    // 8 waves, 4 rows x 64 channels per wave
   }
   if (p.K >= 64) return launch_col<T, 16, 64, 4, 1, false, 2>(p, st);
-  // small channel counts on the large decoder maps (HBM / latency-bound: a tile is a prologue, a handful of MFMAs and an epilogue):
-  // 32 x 16 pixel tiles halve the number of those fixed costs per byte (VK_COL_TALL=0 restores the 16 x 16 tile for A/B runs)
-  static const bool tall = !(getenv("VK_COL_TALL") && atoi(getenv("VK_COL_TALL")) == 0);
-  const bool big_map = (long)p.H * p.W >= 128 * 128 && p.H % 32 == 0;
-  if (p.K >= 32) return (tall && big_map) ? launch_col<T, 32, 32, 4, 1, false, 2>(p, st) : launch_col<T, 16, 32, 4, 1, false, 2>(p, st);
-  return (tall && big_map) ? launch_col<T, 32, 16, 4, 1, false, 2>(p, st) : launch_col<T, 16, 16, 4, 1, false, 2>(p, st);
+  // measured and rejected (r02): 32 x 16 pixel tiles for K <= 32 on the 256x256 / 512x512 maps (half the prologues / epilogues per
+  // byte): dec3.conv1 forward 265 -> 255 us, dec4.conv1 244 -> 243 us, dec3.conv2 data gradient + reduce 109 -> 131 us
+  if (p.K >= 32) return launch_col<T, 16, 32, 4, 1, false, 2>(p, st);
+  return launch_col<T, 16, 16, 4, 1, false, 2>(p, st);
 }
 
 template <typename T>

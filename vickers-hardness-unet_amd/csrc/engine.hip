@@ -1005,13 +1005,15 @@ int backward_decoder(vk_unet* h, int i, hipStream_t st) {
     g_skip = stem.g;
   }
   // conv2 unit (its gradient was pre-masked/pre-reduced by the producer when that kernel supports the fusion)
+  // Order inside a unit: BN backward -> DATA gradient -> weight gradient.  The weight gradient only feeds the optimizer; issued
+  // after the data gradient it can run (side stream, vk_unet_set_side_stream) beside the HBM-bound BatchNorm backward of the
+  // NEXT layer instead of beside an MFMA-bound data gradient.
   RET_IF(bn_relu_bwd_inplace(h, c2, h->g_prereduced[d.conv2] != 0, st));
-  RET_IF(conv_wgrad(h, c2, to_src(bn_act(h, c1)), null_src(), st));
   bool fused1 = false;
   RET_IF(conv_dgrad_into(h, c2, c1, &fused1, st));
+  RET_IF(conv_wgrad(h, c2, to_src(bn_act(h, c1)), null_src(), st));
   // conv1 unit
   RET_IF(bn_relu_bwd_inplace(h, c1, fused1, st));
-  RET_IF(conv_wgrad(h, c1, to_src(xprev, 1), d.Cskip ? to_src(skip) : null_src(), st));
   // data gradient with the nearest-x2 upsample backward fused into its epilogue (the full-resolution d_up never exists)
   // and, for i > 0, the BN+ReLU backward reduce of the previous decoder block's conv2;
   // shapes the tile kernels do not cover fall back to dgrad + a separate 2x2-sum pass
@@ -1024,12 +1026,15 @@ int backward_decoder(vk_unet* h, int i, hipStream_t st) {
     const int rc = vk_conv_dgrad_fused(&dd, dgrad_weights(h, c1), g_prev, d.Cskip ? g_skip : nullptr, d.Cskip ? d.Cup : 0, 1,
                                        want_bnr ? &r : nullptr, st);
     if (rc == VK_OK && want_bnr) h->g_prereduced[h->decs[i - 1].conv2] = 1;
-    if (rc != VK_ERR_UNSUPPORTED) return rc;
+    if (rc != VK_OK && rc != VK_ERR_UNSUPPORTED) return rc;
+    if (rc == VK_ERR_UNSUPPORTED) {
+      void* dup = h->ws + h->off_dup;
+      if (d.Cskip) RET_IF(conv_dgrad(h, c1, dup, g_skip, d.Cup, 0, st));
+      else RET_IF(conv_dgrad(h, c1, dup, nullptr, 0, 0, st));
+      RET_IF(vk_upsample2x_bwd(h->cfg.dtype, N, d.H, d.H, d.Cup, dup, g_prev, 0, st));
+    }
   }
-  void* dup = h->ws + h->off_dup;
-  if (d.Cskip) RET_IF(conv_dgrad(h, c1, dup, g_skip, d.Cup, 0, st));
-  else RET_IF(conv_dgrad(h, c1, dup, nullptr, 0, 0, st));
-  return vk_upsample2x_bwd(h->cfg.dtype, N, d.H, d.H, d.Cup, dup, g_prev, 0, st);
+  return conv_wgrad(h, c1, to_src(xprev, 1), d.Cskip ? to_src(skip) : null_src(), st);
 }
 
 int backward_block(vk_unet* h, int bi, hipStream_t st) {
@@ -1065,21 +1070,21 @@ int backward_block(vk_unet* h, int bi, hipStream_t st) {
     RET_IF(vk_bn_bwd_coeffs(k.C, bd.bsums, bd.count, h->params + bd.g_off, bd.mean, bd.invstd, h->grads + bd.g_off, h->grads + bd.b_off, bd.coef, st));
     RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, cd.z, 2, nullptr, nullptr, k.out, bd.coef, cd.g, nullptr, 0, st));
   }
-  // conv2
-  RET_IF(conv_wgrad(h, c2, to_src(bn_act(h, c1)), null_src(), st));
+  // conv2 (data gradient first, weight gradient after it: see backward_decoder)
   bool fused1 = false;
   RET_IF(conv_dgrad_into(h, c2, c1, &fused1, st));
+  RET_IF(conv_wgrad(h, c2, to_src(bn_act(h, c1)), null_src(), st));
   // conv1
   RET_IF(bn_relu_bwd_inplace(h, c1, fused1, st));
-  RET_IF(conv_wgrad(h, c1, to_src(xin), null_src(), st));
   // gin was written by the identity shortcut above or (downsample blocks) by the decoder skip gradient
   RET_IF(conv_dgrad(h, c1, gin, nullptr, 0, 1, st));
   if (k.convd >= 0) {
     ConvL& cd = h->convs[k.convd];
-    RET_IF(conv_wgrad(h, cd, to_src(xin), null_src(), st));
     RET_IF(conv_dgrad(h, cd, gin, nullptr, 0, 1, st));
+    RET_IF(conv_wgrad(h, c1, to_src(xin), null_src(), st));
+    return conv_wgrad(h, cd, to_src(xin), null_src(), st);
   }
-  return VK_OK;
+  return conv_wgrad(h, c1, to_src(xin), null_src(), st);
 }
 
 int backward_stem(vk_unet* h, hipStream_t st) {

@@ -97,6 +97,9 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
   // staging registers: one set (tile t+1 in flight under the MFMAs of tile t) or, in the small-channel WS configurations whose
   // tiles are a few MFMAs long, two sets (tiles t+1 and t+2 in flight: an HBM round trip is longer than one tile's work)
   constexpr int DEPTH = (WS || KT <= 32) ? 2 : 1;
+  // measured and rejected (r02): the next tile's LDS writes between the 32-pixel steps instead of after the last one — L1 / L2 shapes
+  // 60 -> 66 us (the writes then wait for HBM loads that the remaining steps used to cover), others unchanged
+  constexpr bool STORE_MID = false;
   u32x4_t zreg[DEPTH][ZPASS], vreg[DEPTH][VPASS];
   uint32_t vmask[DEPTH] = {};
 
@@ -282,15 +285,21 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
       if (tl < p.ntiles && !(dbg & 1)) load_tile(tl, zl, vl, ml);
       const char* Zs = smem + (it & 1) * STAGE;
       const char* Vs = Zs + PX * ZSB;
+      bool stored = false;
       if (!(dbg & 4)) {
         if (WS) {
           compute_step(Zs, Vs, wave, hsel_c);
         } else {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) compute_step(Zs, Vs, ks, hsel_c);
+          // the next tile's LDS writes (other stage buffer) go between the 32-pixel steps instead of after the last one: the
+          // ds_write_b128 transfers then run beside the MFMAs of the remaining steps instead of in front of the barrier
+          compute_step(Zs, Vs, 0, hsel_c);
+          compute_step(Zs, Vs, 1, hsel_c);
+          if (STORE_MID && more && !(dbg & 2)) { store_tile((it + 1) & 1, zs, vs, ms); stored = true; }
+          compute_step(Zs, Vs, 2, hsel_c);
+          compute_step(Zs, Vs, 3, hsel_c);
         }
       }
-      if (more && !(dbg & 2)) store_tile((it + 1) & 1, zs, vs, ms);
+      if (!stored && more && !(dbg & 2)) store_tile((it + 1) & 1, zs, vs, ms);
       if (!(dbg & 8)) __syncthreads();
     };
     for (int it = 0; t < p.ntiles; t += p.splits, ++it) {
