@@ -99,14 +99,34 @@ def conv_run(d, w, y, y1=None, split=0, acc=0, stats=None, plain=False):
     return packed
 
 
-@pytest.fixture(params=["tile", "tile_alt1", "tile_alt2", "tile_alt3", "tile_alt7", "tile_alt8", "tap"])
+@pytest.fixture(params=["tile", "tile_alt1", "tile_alt2", "tile_alt3", "tile_alt7", "tile_alt8", "tile_persist", "tap"])
 def conv_path(request, monkeypatch):
     """tile: 3x3 stride-1 tile kernels with halo-pack weights (alt1/2/3/7/8: each tile shape of the K >= 128 class forced);
+    tile_persist: the persistent form of the K < 128 tile kernels forced onto the small test shapes, THREE workgroups walking all
+    tiles (next tile's halo prefetched under the current tile's last stage and epilogue);
     tap: the tap-by-tap implicit-GEMM kernel with plain weights."""
     if request.param.startswith("tile_alt"):
         monkeypatch.setenv("VK_COL_ALT", request.param[-1])
     else:
         monkeypatch.delenv("VK_COL_ALT", raising=False)
+    if request.param == "tile_persist":
+        monkeypatch.setenv("VK_COL_PERSIST", "2")
+        monkeypatch.setenv("VK_COL_PERSIST_GRID", "3")
+    else:
+        monkeypatch.setenv("VK_COL_PERSIST", "0")          # the one-tile-per-workgroup kernels (full-size model tests run the default)
+        monkeypatch.delenv("VK_COL_PERSIST_GRID", raising=False)
+    return request.param
+
+
+@pytest.fixture(params=["one_tile", "persistent"])
+def persist(request, monkeypatch):
+    """The fused data-gradient epilogues (channel split, 2x2 pooling, BN+ReLU-backward reduce, accumulate) through both forms of
+    the K < 128 tile kernels: one tile per workgroup, and three persistent workgroups walking all tiles."""
+    if request.param == "persistent":
+        monkeypatch.setenv("VK_COL_PERSIST", "2")
+        monkeypatch.setenv("VK_COL_PERSIST_GRID", "3")
+    else:
+        monkeypatch.setenv("VK_COL_PERSIST", "0")
     return request.param
 
 
@@ -136,7 +156,7 @@ CONV_CASES = [
 def test_conv_fwd(case, dtn, conv_path):
     dt = DT[dtn]
     _, N, H, Cc, K, R, stride, pad, affine = case
-    if conv_path.startswith("tile_alt") and K < 128:
+    if (conv_path.startswith("tile_alt") and K < 128) or (conv_path == "tile_persist" and K >= 128):
         pytest.skip("alternative tile shapes exist for K >= 128 only")
     Ho = (H + 2 * pad - R) // stride + 1
     x = gen(N, Cc, H, H, seed=1)
@@ -233,7 +253,7 @@ def test_conv_fwd_upsample_concat(shape, dtn, conv_path):
     """decoder conv1: nearest x2 upsample of src0 (with BN+ReLU prologue) concatenated with a skip."""
     dt = DT[dtn]
     N, H, Cup, Cskip, K = shape
-    if conv_path.startswith("tile_alt") and K < 128:
+    if (conv_path.startswith("tile_alt") and K < 128) or (conv_path == "tile_persist" and K >= 128):
         pytest.skip("alternative tile shapes exist for K >= 128 only")
     lo = gen(N, Cup, H // 2, H // 2, seed=5)
     sc_c = 0.5 + torch.rand(Cup, generator=torch.Generator().manual_seed(6))
@@ -303,7 +323,7 @@ DGRAD_CASES = [
 def test_conv_dgrad(case, dtn, conv_path):
     dt = DT[dtn]
     _, N, H, Cc, K, R, stride, pad = case
-    if conv_path.startswith("tile_alt") and Cc < 128:
+    if (conv_path.startswith("tile_alt") and Cc < 128) or (conv_path == "tile_persist" and Cc >= 128):
         pytest.skip("alternative tile shapes exist for >= 128 output channels only")
     Ho = (H + 2 * pad - R) // stride + 1
     w = gen(K, Cc, R, R, seed=21, scale=(2.0 / (K * R * R)) ** 0.5)
@@ -329,7 +349,7 @@ def test_conv_dgrad(case, dtn, conv_path):
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
-def test_conv_dgrad_split(dtn):
+def test_conv_dgrad_split(dtn, persist):
     """concat gradient: channels [0,Cup) -> y, [Cup, Cup+Cskip) -> y1."""
     dt = DT[dtn]
     N, H, Cup, Cskip, K = 1, 16, 128, 64, 64
@@ -351,7 +371,7 @@ def test_conv_dgrad_split(dtn):
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape", [(1, 32, 128, 64, 64), (2, 48, 32, 0, 16), (1, 24, 64, 64, 32), (2, 16, 128, 64, 64)], ids=["d2", "d4_c16", "d3", "d2_small"])
-def test_conv_dgrad_pool2(shape, dtn):
+def test_conv_dgrad_pool2(shape, dtn, persist):
     """decoder conv1 data gradient with the nearest-x2 upsample backward fused: the up part comes out 2x2-summed at
     half resolution, the skip part at full resolution."""
     dt = DT[dtn]
@@ -380,7 +400,7 @@ def test_conv_dgrad_pool2(shape, dtn):
 @pytest.mark.parametrize("dtn", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("pool2", [0, 1])
 @pytest.mark.parametrize("shape", [(2, 24, 64, 0, 32), (2, 16, 128, 64, 64), (1, 32, 256, 128, 128)], ids=["c64", "dec2", "dec1"])
-def test_conv_dgrad_fused_bn_relu_reduce(dtn, pool2, shape):
+def test_conv_dgrad_fused_bn_relu_reduce(dtn, pool2, shape, persist):
     """dgrad whose epilogue already applies the ReLU mask of the layer below and accumulates the BN-backward sums
     (first output part only; the skip part of a concat gradient goes to y1 untouched)."""
     dt = DT[dtn]

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <string>
+#include <type_traits>
 
 #include "vk_common.h"
 
@@ -377,14 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
       if (hp >= HPIX) continue;
       u32x4_t v = areg[i];
       if (aff) {
-        float f[VE];
-        Vec16<T>::unpack(v, f);
-#pragma unroll
-        for (int j = 0; j < VE; ++j) {
-          f[j] = fmaf(f[j], sc[j], sh[j]);
-          if (relu) f[j] = fmaxf(f[j], 0.f);
-        }
-        v = Vec16<T>::pack(f);
+        v = AffineRelu<T>::run(v, sc, sh, relu);
         if (h_full[i] < 0) v = u32x4_t{0, 0, 0, 0};     // zero padding is applied after BN+ReLU
       }
       *reinterpret_cast<u32x4_t*>(Abuf + hp * APS + hv * 16) = v;
@@ -638,14 +632,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
       if (hp >= HPIX) continue;
       u32x4_t v = areg[i];
       if (aff) {
-        float f[VE];
-        Vec16<T>::unpack(v, f);
-#pragma unroll
-        for (int j = 0; j < VE; ++j) {
-          f[j] = fmaf(f[j], sc[j], sh[j]);
-          if (relu) f[j] = fmaxf(f[j], 0.f);
-        }
-        v = Vec16<T>::pack(f);
+        v = AffineRelu<T>::run(v, sc, sh, relu);
         if (h_full[i] < 0) v = u32x4_t{0, 0, 0, 0};     // zero padding is applied after BN+ReLU
       }
       *reinterpret_cast<u32x4_t*>(A + hp * APS + hv * 16) = v;
@@ -780,6 +767,211 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
 #endif
 }
 
+// ---- persistent form of the column-staged kernel for the K < 128 classes (layer1, decoder blocks 2-4: thousands of tiles, each a
+// prologue, 3-18 pipeline stages and an epilogue — HBM / latency-bound).  A workgroup walks tiles t = blockIdx.x, + gridDim.x, ...
+// and requests the NEXT tile's first halo chunk (global -> registers) during the last chunk of the current tile, so that the HBM
+// round trip of a tile's prologue runs under the previous tile's MFMAs and epilogue instead of in front of its own; where the
+// epilogue's LDS image ends below the weight buffers (BN <= 32) the next tile's first weight stage is in flight under the epilogue
+// too.  Same arithmetic, same operand order, same per-tile statistics atomics as conv3x3_col_kernel: results are bit-identical.
+template <typename T, int TH, int BN, int WGM, int WGN, int MINW>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_colp_kernel(const HaloParams p) {
+  using Cfg = ColCfg<T, TH, BN, WGM, WGN, false>;
+  constexpr int EB = Cfg::EB, VE = Cfg::VE, CK = Cfg::CK, HPIX = Cfg::HPIX, NPV = Cfg::NPV, NT = Cfg::NT, NW = Cfg::NW;
+  constexpr int TP = Cfg::TP, TC = Cfg::TC, APS = Cfg::APS, NPIECE = Cfg::NPIECE;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Abuf = smem;
+  char* const Bbuf = smem + Cfg::A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsp = p.N * p.tiles_y * p.tiles_x;               // spatial tiles
+  const int total = nsp * p.kyn;                             // x channel tiles (kyn >= 1 here)
+  const bool xcd_runs = (nsp & 7) == 0 && (gridDim.x & 7) == 0 && p.kyn == 1;
+
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.s0.ptr, p.s0.bytes);
+  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.s1.ptr ? p.s1.ptr : p.s0.ptr, p.s1.ptr ? p.s1.bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
+
+  const int hv = tid & 3;
+  const int Hh = p.H >> 1, Wh = p.W >> 1;
+  // tile geometry: current tile and the one being prefetched
+  struct TileGeo { int n, y0, x0, n0; };
+  auto decode = [&](int t) {
+    TileGeo g;
+    const int ky = t % p.kyn;
+    int bt = t / p.kyn;
+    if (xcd_runs) bt = (bt & 7) * (nsp >> 3) + (bt >> 3);    // every XCD (its own L2) walks a contiguous run of tiles
+    const int tx = bt % p.tiles_x;
+    bt /= p.tiles_x;
+    const int ty = bt % p.tiles_y;
+    g.n = bt / p.tiles_y;
+    g.y0 = ty * TH; g.x0 = tx * 16; g.n0 = ky * BN;
+    return g;
+  };
+  auto halo_index = [&](const TileGeo& g, int (&hf)[NPV], int (&hh)[NPV]) {
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int hp = (tid >> 2) + i * (NT / 4);
+      const int hy = hp / 18, hx = hp - hy * 18;
+      const int y = g.y0 - 1 + hy, x = g.x0 - 1 + hx;
+      const bool ok = hp < HPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      hf[i] = ok ? (g.n * p.H + y) * p.W + x : -1;
+      hh[i] = ok ? (g.n * Hh + (y >> 1)) * Wh + (x >> 1) : -1;
+    }
+  };
+  int h_full[NPV], h_half[NPV], h_full_n[NPV], h_half_n[NPV];
+  u32x4_t areg[NPV];
+  float sc[VE], sh[VE];
+  bool aff = false, relu = false;
+
+  auto load_halo = [&](int cc, const int (&hf)[NPV], const int (&hh)[NPV]) {
+    const int c = cc * CK;
+    const bool first = c < p.s0.C;
+    const HaloSrc& sd = first ? p.s0 : p.s1;
+    const int cl = (first ? c : c - p.s0.C) + hv * VE;
+    aff = sd.scale != nullptr;
+    relu = sd.relu != 0;
+    if (aff) {
+#pragma unroll
+      for (int j = 0; j < VE; j += 4) {
+        const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(sd.scale + cl + j);
+        const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(sd.shift + cl + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[j + e] = s4[e]; sh[j + e] = h4[e]; }
+      }
+    }
+    const bool up = sd.up != 0;
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int pix = up ? hh[i] : hf[i];
+      const uint32_t off = (uint32_t)(pix * sd.C + cl) * (uint32_t)EB;
+      if (first) areg[i] = buf_load16(rs0, pix >= 0 ? off : kOOB);
+      else areg[i] = buf_load16(rs1, pix >= 0 ? off : kOOB);
+    }
+  };
+  auto store_halo = [&](char* A, const int (&hf)[NPV]) {
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int hp = (tid >> 2) + i * (NT / 4);
+      if (hp >= HPIX) continue;
+      u32x4_t v = areg[i];
+      if (aff) {
+        v = AffineRelu<T>::run(v, sc, sh, relu);
+        if (hf[i] < 0) v = u32x4_t{0, 0, 0, 0};         // zero padding is applied after BN+ReLU
+      }
+      *reinterpret_cast<u32x4_t*>(A + hp * APS + hv * 16) = v;
+    }
+  };
+  const uint32_t slab_bytes = (uint32_t)p.K * 64u;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto dma_b = [&](int n0, int cc, int s, int buf) {
+#pragma unroll
+    for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
+      const int pc = wave + i * NW;
+      if (NPIECE % NW == 0 || pc < NPIECE) {
+        const int r = pc / (BN / 16), sub = pc - r * (BN / 16);
+        const int tap = p.flip ? 8 - (3 * r + s) : 3 * r + s;
+        const uint32_t goff = (uint32_t)(cc * 9 + tap) * slab_bytes + (uint32_t)(n0 + sub * 16) * 64u;
+        char* dst = Bbuf + buf * Cfg::B_BYTES + (r * BN + sub * 16) * 64;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, lane16, goff, 0, 0);
+      }
+    }
+  };
+
+  const int wrow0 = (wave / WGN) * TP;
+  const int wch0 = (wave % WGN) * (TC * 16);
+  const int li = lane & 15, kg = lane >> 4;
+  const int a_lane = (wrow0 * 18 + li) * APS + kg * 16;
+  const int b_lane = (wch0 + li) * 64 + ((kg ^ swz(li)) << 4);
+  f32x4_t acc[TC][TP];
+
+  auto compute = [&](const char* A, const char* B) {
+    u32x4_t X[TP + 2], W[3][TC];
+#pragma unroll
+    for (int h = 0; h < TP + 2; ++h) X[h] = *reinterpret_cast<const u32x4_t*>(A + h * (18 * APS));
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int a = 0; a < TC; ++a) W[r][a] = *reinterpret_cast<const u32x4_t*>(B + (r * BN + a * 16) * 64);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = Mma<T>::run(W[r][a], X[b + r], acc[a][b]);
+    constexpr int NM = TC * TP * (sizeof(T) == 4 ? 4 : 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, TP + 2 + TC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, TC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, TC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+  };
+
+  int t = blockIdx.x;
+  if (t >= total) return;                                   // (grid is never larger than the tile count)
+  TileGeo g = decode(t);
+  halo_index(g, h_full, h_half);
+  load_halo(0, h_full, h_half);
+  int st = 0;                                               // running stage counter: weight buffer = st & 1, across tiles
+  for (;;) {
+    // ---- entry: the tile's first halo chunk is in areg (requested during the previous tile's last stage), no LDS-DMA is pending
+    dma_b(g.n0, 0, 0, st & 1);                              // first weight stage: in flight while the halo is transformed and written
+    store_halo(Abuf, h_full);
+    __syncthreads();                                        // also drains the LDS-DMA (vmcnt(0))
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int tn = t + (int)gridDim.x;
+    const bool more_tiles = tn < total;
+    TileGeo gn = g;
+    const char* const A = Abuf + a_lane;
+    // one pipeline stage.  LAST = the tile's last channel chunk, written out separately so that its final stage contains NO LDS-DMA:
+    // the barrier closing it and the barriers of the epilogue then need no vmcnt(0), and the next tile's halo loads (plain global
+    // loads into registers) stay in flight across all of them, until store_halo at the top of the next iteration consumes them.
+    auto stage = [&](int cc, auto s_c, auto last_c) {
+      constexpr int s = decltype(s_c)::value;
+      constexpr bool LAST = decltype(last_c)::value;
+      if (s < 2) dma_b(g.n0, cc, s + 1, (st + 1) & 1);
+      else if (!LAST) dma_b(g.n0, cc + 1, 0, (st + 1) & 1);
+      if (s == 0 && !LAST) load_halo(cc + 1, h_full, h_half);
+      if (s == 2 && LAST && more_tiles) {
+        gn = decode(tn);
+        halo_index(gn, h_full_n, h_half_n);
+        load_halo(0, h_full_n, h_half_n);
+      }
+      compute(A + s * APS, Bbuf + (st & 1) * Cfg::B_BYTES + b_lane);
+      if (s == 2 && !LAST) {
+        __syncthreads();                                    // every wave is done reading this chunk's halo
+        store_halo(Abuf, h_full);
+      }
+      __syncthreads();
+      ++st;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    for (int cc = 0; cc + 1 < p.nchunks; ++cc) {
+      stage(cc, I0{}, std::false_type{});
+      stage(cc, I1{}, std::false_type{});
+      stage(cc, I2{}, std::false_type{});
+    }
+    stage(p.nchunks - 1, I0{}, std::true_type{});
+    stage(p.nchunks - 1, I1{}, std::true_type{});
+    stage(p.nchunks - 1, I2{}, std::true_type{});
+    // aff / relu / sc / sh now describe the prefetched chunk (chunk 0 of the next tile): exactly what its store_halo needs
+    halo_epilogue<T, TH, BN, TP, TC, NT, (BN <= 64 && TH == 16)>(smem, acc, p, g.n, g.y0, g.x0, g.n0, wrow0, wch0);
+    if (!more_tiles) break;
+    __syncthreads();                                        // epilogue reads of the LDS tile are over: the halo image may be rewritten
+    t = tn;
+    g = gn;
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) { h_full[i] = h_full_n[i]; h_half[i] = h_half_n[i]; }
+  }
+}
+
 // ---- C == 16 (16-bit types): decoder block 4 conv2 and the data gradients whose reduction runs over 16 channels.
 // A pixel is 32 bytes, so one K=32 MFMA step covers TWO taps x 16 channels; 9 taps = 5 steps (the 10th half reads zeros).
 // Everything (18x18 halo, all 9 taps of weights) is staged once: these layers are HBM-bound, the kernel is a
@@ -862,14 +1054,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const HaloParams p) {
     if (hp >= HPIX) continue;
     u32x4_t v = areg[i];
     if (aff) {
-      float f[VE];
-      Vec16<T>::unpack(v, f);
-#pragma unroll
-      for (int j = 0; j < VE; ++j) {
-        f[j] = fmaf(f[j], sc[j], sh[j]);
-        if (relu) f[j] = fmaxf(f[j], 0.f);
-      }
-      v = Vec16<T>::pack(f);
+      v = AffineRelu<T>::run(v, sc, sh, relu);
       if (!aok[i]) v = u32x4_t{0, 0, 0, 0};
     }
     *reinterpret_cast<u32x4_t*>(Abuf + hp * APS + hv * 16) = v;
@@ -1043,6 +1228,57 @@ static int launch_col(HaloParams p, hipStream_t st) {
   return VK_OK;
 }
 
+// persistent launch of conv3x3_colp_kernel: as many workgroups as stay resident (LDS-limited), at least two tiles each
+template <typename T, int TH, int BN, int WGM, int WGN, int MINW>
+static int launch_colp(HaloParams p, hipStream_t st) {
+  using Cfg = ColCfg<T, TH, BN, WGM, WGN, false>;
+  p.tiles_x = (p.W + 15) / 16;
+  p.tiles_y = (p.H + TH - 1) / TH;
+  p.kyn = (p.K + BN - 1) / BN;
+  p.ksplit = 1;
+  const long total = (long)p.N * p.tiles_y * p.tiles_x * p.kyn;
+  int per_cu = (160 * 1024) / Cfg::SMEM;
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  long g = 256L * per_cu;
+  if (const char* e = getenv("VK_COL_PERSIST_GRID")) g = atol(e) > 0 ? atol(e) : g;      // tests: few workgroups, many tiles each
+  if (g > total) g = total;
+  static bool attr_done = false;
+  if (!attr_done && Cfg::SMEM > 64 * 1024) {
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_colp_kernel<T, TH, BN, WGM, WGN, MINW>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+    attr_done = true;
+  }
+  {
+    static const std::string tag_f = std::string("col_") + (sizeof(T) == 4 ? "f32" : "16b") + "_t" + std::to_string(TH) + "_bn" + std::to_string(BN) +
+                                     "_w" + std::to_string(WGM * WGN);
+    static const std::string tag_d = tag_f + "_dgrad";
+    const double macs = (double)p.N * p.H * p.W * p.K * 9.0 * p.C;
+    const double bytes = ((double)p.N * p.H * p.W * (p.C + p.K) + 9.0 * p.K * p.C) * sizeof(T);
+    const std::string& btag = p.flip ? tag_d : tag_f;
+    const std::string dtag = getenv("VK_PROF_DETAIL") ? btag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) : btag;
+    vkh::ProfScope ps(dtag.c_str(), st, 2.0 * macs, bytes);
+    hipLaunchKernelGGL((conv3x3_colp_kernel<T, TH, BN, WGM, WGN, MINW>), dim3((unsigned)g), dim3(Cfg::NT), Cfg::SMEM, st, p);
+  }
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+// the K < 128 classes: persistent kernel when a workgroup gets several tiles and nothing needs the split-K path
+template <typename T, int BN>
+static int launch_small(const HaloParams& p, hipStream_t st) {
+  const long total = (long)p.N * ((p.H + 15) / 16) * ((p.W + 15) / 16) * ((p.K + BN - 1) / BN);
+  // OFF by default (measured, r02): the prefetched halo + second index set cost 40-50 registers, i.e. 4 -> 2 (BN = 16) and 3 -> 2
+  // (BN = 32) workgroups per CU: dec4.conv1 forward 242 -> 325 us, dec3.conv2 84 -> 108 us; on BN = 64 (equal occupancy) it gains
+  // 2-3 % (layer1 forward 61.6 -> 59.6 us) — the co-resident workgroups already hide each other's prologue.  Kept as an opt-in and
+  // tested (VK_COL_PERSIST=N: from N tiles on).
+  const char* pe = getenv("VK_COL_PERSIST");
+  const long min_tiles = pe ? (atol(pe) == 0 ? -1 : atol(pe)) : -1;
+  const bool splitk_wanted = p.slab && !p.stats && !p.bnr_z && !p.accumulate && !p.pool2 && p.split == 0 && total < 128;
+  if (min_tiles > 0 && !splitk_wanted && total >= min_tiles) return launch_colp<T, 16, BN, 4, 1, 2>(p, st);
+  return launch_col<T, 16, BN, 4, 1, false, 2>(p, st);
+}
+
 // tile selection for the column-staged kernels.  VK_COL_ALT (diagnostic / tests) forces a shape of the K >= 128 class:
 //   1: 4 waves, 16x16x128, 8 rows x 64 channels per wave (one wave per SIMD);  2: the 8-wave 16x16x128 tile;  3: the 4-wave 8x16x128 tile;
 //   7: the 8-wave 8x16x128 tile;  8: the 4-wave 16x16x64 tile
@@ -1056,7 +1292,7 @@ static int col_select(const HaloParams& p, hipStream_t st) {
     if (alt == 1) return launch_col<T, 16, 128, 2, 2, true, 1>(p, st);
     // a short reduction onto a channel count that is not a multiple of 128 (the concat gradient of decoder block 2: 64 -> 192):
     // 64-channel tiles waste no half-empty channel tile (201 -> 156 us stand-alone)
-    if (alt == 8 || (alt == 0 && p.nchunks <= 2 && p.K % 128 != 0)) return launch_col<T, 16, 64, 4, 1, false, 2>(p, st);
+    if (alt == 8 || (alt == 0 && p.nchunks <= 2 && p.K % 128 != 0)) return launch_small<T, 64>(p, st);
     // a reduction of one or two channel chunks (the concat gradients of decoder blocks 2/3: HBM / epilogue-bound, thousands of
     // tiles): the 4-wave 8x16x128 tile, two workgroups per CU
     if (alt == 3 || (alt != 2 && alt != 7 && p.nchunks <= 2)) return launch_col<T, 8, 128, 2, 2, false, 2>(p, st);
@@ -1065,11 +1301,11 @@ static int col_select(const HaloParams& p, hipStream_t st) {
     if (alt == 7 || (alt != 2 && tiles16 * kt < 256)) return launch_col<T, 8, 128, 2, 4, true, 2>(p, st);
     return launch_col<T, 16, 128, 4, 2, true, 2>(p, st);                    // 8 waves, 4 rows x 64 channels per wave
   }
-  if (p.K >= 64) return launch_col<T, 16, 64, 4, 1, false, 2>(p, st);
+  if (p.K >= 64) return launch_small<T, 64>(p, st);
   // measured and rejected (r02): 32 x 16 pixel tiles for K <= 32 on the 256x256 / 512x512 maps (half the prologues / epilogues per
   // byte): dec3.conv1 forward 265 -> 255 us, dec4.conv1 244 -> 243 us, dec3.conv2 data gradient + reduce 109 -> 131 us
-  if (p.K >= 32) return launch_col<T, 16, 32, 4, 1, false, 2>(p, st);
-  return launch_col<T, 16, 16, 4, 1, false, 2>(p, st);
+  if (p.K >= 32) return launch_small<T, 32>(p, st);
+  return launch_small<T, 16>(p, st);
 }
 
 template <typename T>

@@ -284,14 +284,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int i = 0; i < APASS; ++i) {
       u32x4_t v = areg[i];
       if (pend_affine) {
-        float f[VE];
-        Vec16<T>::unpack(v, f);
-#pragma unroll
-        for (int j = 0; j < VE; ++j) {
-          f[j] = fmaf(f[j], sc[j], sh[j]);
-          if (pend_relu) f[j] = fmaxf(f[j], 0.f);
-        }
-        v = Vec16<T>::pack(f);
+        v = AffineRelu<T>::run(v, sc, sh, pend_relu);
         if (!((vmask >> i) & 1u)) v = u32x4_t{0, 0, 0, 0};
       }
       *reinterpret_cast<u32x4_t*>(As + (a_row + i * RPP) * RSB + a_vec * 16) = v;

@@ -18,6 +18,10 @@ typedef __attribute__((ext_vector_type(4))) float    f32x4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 typedef __attribute__((ext_vector_type(4))) short    s16x4_t;
+typedef __attribute__((ext_vector_type(2))) float    f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16   bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(2))) short    s16x2_t;
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {
@@ -40,6 +44,7 @@ template <> struct ElemTraits<f16_t> {
 // of the whole vector and silently returns element 0.  Go through these by-value helpers.
 __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ f16x2_t as_f16x2(uint32_t u) { return __builtin_bit_cast(f16x2_t, u); }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return as_f32(b << 16); }
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
   // plain cast => v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even, NaN stays NaN)
@@ -93,9 +98,11 @@ template <> struct Vec16<bf16_t> {
     }
   }
   static __device__ __forceinline__ u32x4_t pack(const float* f) {
+    // a vector conversion of the PAIR is one v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN); two scalar casts + shift + or
+    // were four VALU instructions per pair — a quarter of the BN+ReLU operand transform of the small-channel convolutions
     u32x4_t v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = f32_to_bf16_bits(f[2 * i]) | (f32_to_bf16_bits(f[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * i], f[2 * i + 1]}, bf16x2_t));
     return v;
   }
 };
@@ -110,8 +117,57 @@ template <> struct Vec16<f16_t> {
   static __device__ __forceinline__ u32x4_t pack(const float* f) {
     u32x4_t v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = f32_to_f16_bits(f[2 * i]) | (f32_to_f16_bits(f[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * i], f[2 * i + 1]}, f16x2_t));   // v_cvt_pk_f16_f32? (RNE)
     return v;
+  }
+};
+
+// ---------------------------------------------------------------- BatchNorm apply (+ReLU) on one 16-byte operand vector
+// v' = relu?(v * sc + sh), the transform every convolution applies to its operand while staging it (train-mode BatchNorm cannot
+// be fused into the producing convolution).  On the small-channel decoder layers this VALU block is a real share of the kernel,
+// so the 16-bit forms are written for the fewest instructions per PAIR of elements: 2 to unpack, ONE v_pk_fma_f32, ONE
+// v_cvt_pk_*, ONE v_pk_max_i16 — ReLU on the packed result: a negative 16-bit float has its sign bit set, i.e. is a negative
+// int16, so max(., 0) as int16 clears exactly the negatives (and -0); rounding is monotonic, so relu-then-round == round-then-relu.
+// `relu` is a runtime flag: without it the floor is INT16_MIN and the max is the identity (no branch).
+template <typename T> struct AffineRelu;
+template <> struct AffineRelu<float> {
+  static __device__ __forceinline__ u32x4_t run(u32x4_t v, const float* sc, const float* sh, bool relu) {
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f = fmaf(as_f32(v[j]), sc[j], sh[j]);
+      if (relu) f = fmaxf(f, 0.f);
+      o[j] = as_u32(f);
+    }
+    return o;
+  }
+};
+template <> struct AffineRelu<bf16_t> {
+  static __device__ __forceinline__ u32x4_t run(u32x4_t v, const float* sc, const float* sh, bool relu) {
+    const s16x2_t floor = relu ? s16x2_t{0, 0} : s16x2_t{(short)-32768, (short)-32768};
+    u32x4_t o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x2_t x = {as_f32(v[i] << 16), as_f32(v[i] & 0xffff0000u)};
+      x = __builtin_elementwise_fma(x, f32x2_t{sc[2 * i], sc[2 * i + 1]}, f32x2_t{sh[2 * i], sh[2 * i + 1]});
+      const s16x2_t r = __builtin_bit_cast(s16x2_t, __builtin_convertvector(x, bf16x2_t));
+      o[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(r, floor));
+    }
+    return o;
+  }
+};
+template <> struct AffineRelu<f16_t> {
+  static __device__ __forceinline__ u32x4_t run(u32x4_t v, const float* sc, const float* sh, bool relu) {
+    const s16x2_t floor = relu ? s16x2_t{0, 0} : s16x2_t{(short)-32768, (short)-32768};
+    u32x4_t o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x2_t x = __builtin_convertvector(as_f16x2(v[i]), f32x2_t);      // by-value helper: see the bit_cast note above
+      x = __builtin_elementwise_fma(x, f32x2_t{sc[2 * i], sc[2 * i + 1]}, f32x2_t{sh[2 * i], sh[2 * i + 1]});
+      const s16x2_t r = __builtin_bit_cast(s16x2_t, __builtin_convertvector(x, f16x2_t));
+      o[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(r, floor));
+    }
+    return o;
   }
 };
 

@@ -161,14 +161,7 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
       const int v = tid + i * NT;
       u32x4_t x = vreg[i];
       if (affine) {
-        float f[VE];
-        Vec16<T>::unpack(x, f);
-#pragma unroll
-        for (int j = 0; j < VE; ++j) {
-          f[j] = fmaf(f[j], sc[j], sh[j]);
-          if (relu) f[j] = fmaxf(f[j], 0.f);
-        }
-        x = Vec16<T>::pack(f);
+        x = AffineRelu<T>::run(x, sc, sh, relu);
         if (!((vmask >> i) & 1u)) x = u32x4_t{0, 0, 0, 0};
       }
       if (v < HPIX * VV) *reinterpret_cast<u32x4_t*>(Vs + (v / VV) * VSB + (v % VV) * 16) = x;
