@@ -1,6 +1,6 @@
 """Layer-by-layer comparison of the HIP engine against the oracle (GPU box only; debugging aid).
 
-    python tools/debug_layers.py [--n 2] [--size 64] [--dtype f32|bf16] [--train]
+    python tests/diag/debug_layers.py [--n 2] [--size 64] [--dtype f32|bf16] [--train]
 prints max|err| / max|ref| for every raw conv output z, every block output and (with --train) every
 gradient buffer, so the first diverging kernel is obvious."""
 import argparse
@@ -10,7 +10,7 @@ from pathlib import Path
 
 import torch
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 vk = importlib.import_module("vickers-hardness-unet_amd")
 from oracle import unet_oracle as O  # noqa: E402

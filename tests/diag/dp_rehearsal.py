@@ -1,6 +1,6 @@
 """Two (or more) ranks on ONE GPU through gloo: the data-parallel invariants of vk.make_data_parallel on the real engine.
 
-    torchrun --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29566 tools/dp_rehearsal.py
+    torchrun --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29566 tests/diag/dp_rehearsal.py
 
 Checks on different per-rank batches: (1) after the first backward the reduced gradient buffer of every rank equals — to fp32
 round-off — the sum of the per-rank gradients a single process computes by itself (no reducer); (2) after three optimizer
@@ -15,7 +15,7 @@ from pathlib import Path
 import torch
 import torch.distributed as dist
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 vk = importlib.import_module("vickers-hardness-unet_amd")
 from oracle import unet_oracle as O      # synthetic data + seeding only
 

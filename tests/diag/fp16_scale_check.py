@@ -2,7 +2,7 @@
 import importlib, sys
 from pathlib import Path
 import torch
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 vk = importlib.import_module("vickers-hardness-unet_amd")
 from oracle import unet_oracle as O
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Diagnostic: per-parameter gradient error of the fp32 plan against the CPU oracle, with the oracle ALSO run in float64 as the
 arbiter (which of the two fp32 implementations is closer to exact arithmetic?).
 
-    python tools/grad_err.py [N] [S] [seed]
+    python tests/diag/grad_err.py [N] [S] [seed]
 """
 import copy
 import importlib
@@ -10,7 +10,7 @@ from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 vk = importlib.import_module("vickers-hardness-unet_amd")
 from oracle import unet_oracle as O  # noqa: E402
 

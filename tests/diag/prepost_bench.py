@@ -1,6 +1,6 @@
 """Timing of the pre/post-processing kernels on one MI355X, inputs resident in HBM:
 
-    python tools/prepost_bench.py [--reps 200] [--no-cpu]
+    python tests/diag/prepost_bench.py [--reps 200] [--no-cpu]
 
 Per case: microseconds per launch (HIP events on the launch stream), algorithmic bytes (source bytes the gather can touch +
 destination bytes) / time against the 8 TB/s HBM roofline, the PCIe-inclusive time of the pre-processing call (pageable
@@ -16,7 +16,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 vk = importlib.import_module("vickers-hardness-unet_amd")
 from oracle import prepost_oracle as P      # CPU leg only
 

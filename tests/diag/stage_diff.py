@@ -3,7 +3,7 @@ in one process and report where the intermediate gradient buffers differ."""
 import importlib, os, sys
 from pathlib import Path
 import torch
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 vk = importlib.import_module("vickers-hardness-unet_amd")
 from oracle import unet_oracle as O
 L = vk.lib(); L_ = vk._lib

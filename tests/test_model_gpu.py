@@ -465,7 +465,7 @@ def test_train_gradients_fp32_n8_against_plain_oracle(pair):
     """All 140 parameter gradients against the UNMODIFIED oracle on batches large enough that one ReLU tie cannot move a BatchNorm
     channel (N=8: 64x64 and 128x128).
 
-    Measured with the oracle ALSO run in float64 as the arbiter (tools/grad_err.py, profiles/r02/grad_err.log): at random init this
+    Measured with the oracle ALSO run in float64 as the arbiter (tests/diag/grad_err.py, profiles/r02/grad_err.log): at random init this
     46-BatchNorm-deep network amplifies fp32 round-off to ~1 % of a parameter's gradient in ANY fp32 implementation — the fp32
     oracle itself is 0.4 % (8x64), 0.35 % (8x128), 0.6 % (16x128) and 1.3 % (8x256) away from its own float64 run, growing with
     the number of activations (more near-zero pre-activations on either side of a ReLU), while the engine is 0.9 / 1.4 / 1.6 /
@@ -535,7 +535,7 @@ def test_config5_fp16_train_bs8_1024_properties_and_eval_logits():
         o, n = name_to_off[k]
         assert torch.equal(g1[o:o + n], model.flat_grads[o:o + n]), k
     # the reference's loss scale (GradScaler default 2^16, train.py:610-611) is what makes fp16 work at this size: with
-    # 1 / (8 * 1024 * 1024) = 1.2e-7 per-pixel loss weights the unscaled fp16 gradients underflow (measured, tools/fp16_scale_check.py:
+    # 1 / (8 * 1024 * 1024) = 1.2e-7 per-pixel loss weights the unscaled fp16 gradients underflow (measured, tests/diag/fp16_scale_check.py:
     # cosine with the fp32 plan's gradient 0.933 unscaled, 0.995 with the scale, bf16 0.970)
     def cos(a, b):
         a, b = a.double(), b.double()
