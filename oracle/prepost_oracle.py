@@ -1,5 +1,5 @@
 """CPU restatement (numpy) of the steps either side of ``model(x)`` in the reference's inference wrappers
-(SURVEY.md §8(f) rank 1).  TEST INFRASTRUCTURE ONLY: imported by tests/ and tools/prepost_bench.py's CPU
+(SURVEY.md §8(f) rank 1).  TEST INFRASTRUCTURE ONLY: imported by tests/ (incl. tests/diag/prepost_bench.py)'s CPU
 leg as the checker, never by the product path.
 
 PARITY UNPINNED.  The arithmetic lives in OpenCV (``cv2.resize``), which is not importable in this image,
