@@ -226,21 +226,33 @@ typedef struct {
   int d4;               /* OneOf(flips, rot90), train.py:81-85: 0 none, 1 HorizontalFlip, 2 VerticalFlip, 3 + k = np.rot90(k), k = 0..3 */
   int rotate;           /* Rotate(limit=180, BORDER_CONSTANT), train.py:89: 1 = applied */
   float cos_a, sin_a;   /* of the angle (counter-clockwise, cv2.getRotationMatrix2D about (S/2 - 0.5, S/2 - 0.5)) */
-  int photo;            /* OneOf, train.py:96-100: 0 none, 1 RandomBrightnessContrast, 3 GaussianBlur (2 = CLAHE: refused) */
+  int photo;            /* OneOf, train.py:96-100: 0 none, 1 RandomBrightnessContrast, 2 CLAHE, 3 GaussianBlur */
   float alpha, beta;    /* RandomBrightnessContrast: v' = trunc(clip(v * alpha + beta * 255, 0, 255)) */
   int blur_ksize;       /* GaussianBlur: 3 or 5 (sigma 0 -> cv2's binomial kernels), BORDER_REFLECT_101 */
   float noise_scale;    /* GaussNoise, train.py:104: sigma / 65536 on the 0..255 scale; 0 = not applied */
   uint32_t noise_seed;  /* seed of the counter-based noise field of this sample */
+  int clahe_limit;      /* CLAHE, train.py:98: OpenCV's integer clip limit max(1, int(clip * (S/8)^2 / 256)), clip ~ U(1, 2) */
 } vk_aug_params;
+
+/* CLAHE works on the L channel of an 8-bit RGB <-> L*a*b* conversion done in integer fixed point through three tables the
+ * host builds once (vickers-hardness-unet_amd/augment.py: color_tables) and keeps on the device as int32 [VK_AUG_TABLE_INTS]:
+ * LIN [256] sRGB decode x 4096 | FT [4097] Lab f(t / 4096) x 32768 | ENC [4097] sRGB encode of lin / 4096. */
+#define VK_AUG_TABLE_INTS (256 + 4097 + 4097)
+/* bytes of scratch vk_augment_batch needs for n samples when any of them draws CLAHE: per sample the geometric result as
+ * L, a, b, mask uint8 [S][S][4] and the 8 x 8 tile LUTs uint8 [64][256] */
+size_t vk_augment_workspace_bytes(int n, int size);
 
 /* uint8 BGR [h][w][3] -> uint8 RGB [S][S][3]: cv2.resize(INTER_LINEAR) to nh x nw at (top, left), constant border */
 int vk_letterbox_u8(const vk_letterbox_desc* d, const uint8_t* bgr, uint8_t* rgb_sq, void* stream);
 /* uint8 mask [h][w] (row stride d->src_stride bytes) -> {0,1} [S][S]: (m > 0), cv2.resize(INTER_NEAREST), border 0 */
 int vk_letterbox_mask_u8(const vk_letterbox_desc* d, const uint8_t* mask_hw, uint8_t* mask_sq, void* stream);
 /* images_rgb uint8 [n_items][S][S][3], masks uint8 [n_items][S][S] in {0,1} (device); index_dev int32 [n] (device): the dataset
- * item of every sample; params_host [n]: validated on the host, then copied to params_dev (device scratch, n * sizeof) */
+ * item of every sample; params_host [n]: validated on the host, then copied to params_dev (device scratch, n * sizeof).
+ * color_tables (device, int32 [VK_AUG_TABLE_INTS]) and workspace (device, vk_augment_workspace_bytes(n, size)) are needed only
+ * when a sample has photo == 2 and may be null otherwise; CLAHE needs size % 8 == 0 (8 x 8 tiles without padding). */
 int vk_augment_batch(int n, int size, int n_items, const uint8_t* images_rgb, const uint8_t* masks, const int* index_dev,
-                     const vk_aug_params* params_host, void* params_dev, float* x, float* y, void* stream);
+                     const vk_aug_params* params_host, void* params_dev, const int* color_tables, void* workspace,
+                     size_t workspace_bytes, float* x, float* y, void* stream);
 
 /* NCHW fp32 [N][3][H][W] -> NHWC4 `dtype` */
 int vk_input_transform(vk_dtype dtype, int N, int H, int W, const float* x, void* x4, void* stream);

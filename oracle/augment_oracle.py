@@ -6,7 +6,7 @@ The reference composes albumentations transforms (third-party, absent here, un-p
     A.LongestMaxSize(S, INTER_LINEAR)  A.PadIfNeeded(S, S, BORDER_CONSTANT)                      -> prepost_oracle "train" letterbox
     A.OneOf([HorizontalFlip, VerticalFlip, RandomRotate90], p=0.8)                              -> d4
     A.Rotate(limit=180, border_mode=BORDER_CONSTANT, p=0.6)                                     -> rotate
-    A.OneOf([RandomBrightnessContrast, CLAHE(2.0, (8, 8)), GaussianBlur((3, 5))], p=0.8)        -> photo (CLAHE not built)
+    A.OneOf([RandomBrightnessContrast, CLAHE(2.0, (8, 8)), GaussianBlur((3, 5))], p=0.8)        -> photo
     A.GaussNoise(p=0.3)                                                                         -> noise
     A.Normalize(ImageNet mean / std)   ToTensorV2()                                             -> float32 CHW
 
@@ -26,8 +26,7 @@ libraries' published behaviour [upstream]:
     counter-based hash (splitmix64 of seed / pixel / channel), so that the device kernel and this file produce the SAME noise field
     bit for bit from one 32-bit seed (variance 1 to 1e-9, support +-6 sigma).
   * Normalize: (v - mean * 255) * (1 / (std * 255)) in float32, as albumentations' functional.normalize computes it.
-  * CLAHE is not implemented on the device; the host sampler (vickers-hardness-unet_amd/augment.py) re-normalises the OneOf over the
-    two implemented members and says so.
+  * CLAHE: OpenCV's algorithm on the L channel of an integer 8-bit RGB <-> L*a*b* conversion (section at the end of this file).
 """
 from __future__ import annotations
 
@@ -151,7 +150,118 @@ def augment(img_rgb: np.ndarray, mask01: np.ndarray, p: dict):
     elif p["photo"] == PHOTO_BLUR:
         img = gaussian_blur(np.ascontiguousarray(img), p["blur_ksize"])
     elif p["photo"] == PHOTO_CLAHE:
-        raise NotImplementedError("CLAHE is not part of the device pipeline")
+        img = clahe_rgb(np.ascontiguousarray(img), clahe_limit(p["clahe_clip"], img.shape[0]))
     if p["noise_scale"] > 0:
         img = gauss_noise(np.ascontiguousarray(img), p["noise_scale"], p["noise_seed"])
     return normalize_chw(np.ascontiguousarray(img)), m.astype(F)[None]
+
+
+# ------------------------------------------------------------------------------------------------ CLAHE (train.py:98)
+# A.CLAHE(clip_limit=2.0, tile_grid_size=(8, 8)) [upstream]: clip ~ U(1, 2); RGB -> LAB (cv2, 8-bit), cv2.createCLAHE(clip, (8, 8)).apply(L),
+# LAB -> RGB.  Restated with:
+#   * the CLAHE algorithm of OpenCV's clahe.cpp: per-tile 256-bin histogram, clipLimit = max(1, int(clip * tileArea / 256)), excess
+#     redistributed as `clipped / 256` to every bin plus the residual to every `256 / residual`-th bin, lut = cvRound(cdf * 255 / tileArea)
+#     in float32, bilinear interpolation of the four neighbouring tile LUTs with tile coordinates x / tileW - 0.5 (float32, fixed order);
+#   * an 8-bit RGB <-> CIE L*a*b* conversion (sRGB companding, D65) in INTEGER fixed point through three tables built here with numpy
+#     (and handed to the device kernel as data), so that device and oracle agree bit for bit.  OpenCV's own 8-bit path uses different
+#     fixed-point tables: its L can differ by one level — parity unpinned, as everything cv2 does in this file.
+def color_tables():
+    """(LIN uint16 [256]: sRGB decode x 4096;  FT int32 [4097]: the Lab f() of t / 4096, x 32768;  ENC uint8 [4097]: sRGB encode of lin / 4096)"""
+    v = np.arange(256, dtype=np.float64) / 255.0
+    lin = np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4)
+    LIN = np.rint(lin * 4096.0).astype(np.uint16)
+    t = np.arange(4097, dtype=np.float64) / 4096.0
+    f = np.where(t > 216.0 / 24389.0, np.cbrt(t), (24389.0 / 27.0 * t + 16.0) / 116.0)
+    FT = np.rint(f * 32768.0).astype(np.int32)
+    enc = np.where(t <= 0.0031308, 12.92 * t, 1.055 * t ** (1.0 / 2.4) - 0.055)
+    ENC = np.clip(np.rint(enc * 255.0), 0, 255).astype(np.uint8)
+    return LIN, FT, ENC
+
+
+# rows: X / Xn, Y, Z / Zn of linear sRGB (D65), x 4096, every row summing to exactly 4096 (white maps to t = 4096)
+_M_FWD = np.array([[1777, 1541, 778], [871, 2929, 296], [73, 448, 3575]], dtype=np.int64)
+# inverse: linear R, G, B from (X / Xn, Y, Z / Zn), x 4096 (rows sum to 4096)
+_M_INV = np.array([[12615, -6296, -2223], [-3773, 7684, 185], [217, -836, 4715]], dtype=np.int64)
+
+
+def rgb_to_lab_u8(img: np.ndarray, tabs) -> np.ndarray:
+    LIN, FT, _ = tabs
+    lin = LIN[img].astype(np.int64)                                        # [S][S][3]
+    t = (lin @ _M_FWD.T + 2048) >> 12
+    t = np.clip(t, 0, 4096)
+    f = FT[t].astype(np.int64)
+    fx, fy, fz = f[..., 0], f[..., 1], f[..., 2]
+    L = (116 * fy * 255 - 16 * 255 * 32768 + 50 * 32768) // (100 * 32768)
+    a = ((500 * (fx - fy) + 16384) >> 15) + 128
+    b = ((200 * (fy - fz) + 16384) >> 15) + 128
+    return np.stack([np.clip(L, 0, 255), np.clip(a, 0, 255), np.clip(b, 0, 255)], axis=-1).astype(np.uint8)
+
+
+def lab_to_rgb_u8(lab: np.ndarray, tabs) -> np.ndarray:
+    _, _, ENC = tabs
+    L, a, b = (lab[..., i].astype(np.int64) for i in range(3))
+    fy = ((L * 100 * 32768 + 127) // 255 + 16 * 32768 + 58) // 116
+    fx = fy + ((a - 128) * 32768 + 250) // 500                                # floor division, also for negatives
+    fz = fy - ((b - 128) * 32768 + 100) // 200
+
+    def finv(f):                                                              # t x 4096 from f x 32768
+        cube = (f * f * f + (1 << 32)) >> 33
+        low = ((f * 116 - 16 * 32768) * 27 * 4096 + (24389 * 32768) // 2) // (24389 * 32768)
+        return np.clip(np.where(f > 6780, cube, low), 0, 8192)                # 6 / 29 x 32768 = 6779.6
+
+    t = np.stack([finv(fx), finv(fy), finv(fz)], axis=-1)
+    lin = np.clip((t @ _M_INV.T + 2048) >> 12, 0, 4096)
+    return ENC[lin]
+
+
+def clahe_limit(clip: float, S: int) -> int:
+    ts = S // 8
+    return max(1, int(clip * (ts * ts) / 256.0))                              # clahe.cpp: static_cast<int>(clipLimit * tileSizeTotal / histSize)
+
+
+def clahe_u8(plane: np.ndarray, limit: int) -> np.ndarray:
+    """OpenCV CLAHE on a uint8 [S][S] plane, 8 x 8 tiles (S % 8 == 0), integer clip limit already derived."""
+    S = plane.shape[0]
+    ts = S // 8
+    luts = np.zeros((8, 8, 256), dtype=np.uint8)
+    scale = F(255.0) / F(ts * ts)
+    for ty in range(8):
+        for tx in range(8):
+            h = np.bincount(plane[ty * ts:(ty + 1) * ts, tx * ts:(tx + 1) * ts].ravel(), minlength=256).astype(np.int64)
+            clipped = int(np.maximum(h - limit, 0).sum())
+            h = np.minimum(h, limit)
+            batch, residual = clipped // 256, clipped % 256
+            h += batch
+            if residual:
+                step = max(256 // residual, 1)
+                idx = np.arange(0, 256, step)[:residual]
+                h[idx] += 1
+            cdf = np.cumsum(h)
+            luts[ty, tx] = np.clip(np.rint((cdf.astype(F) * scale).astype(F)), 0, 255).astype(np.uint8)
+    inv = F(1.0) / F(ts)
+    c = np.arange(S, dtype=F)
+    tf = ((c * inv).astype(F) - F(0.5)).astype(F)
+    t1f = np.floor(tf)
+    wa = (tf - t1f).astype(F)
+    wa1 = (F(1.0) - wa).astype(F)
+    t1 = t1f.astype(np.int64)
+    t2 = np.minimum(t1 + 1, 7)
+    t1 = np.maximum(t1, 0)
+    v = plane.astype(np.int64)
+    yy, xx = np.meshgrid(np.arange(S), np.arange(S), indexing="ij")
+    l11 = luts[t1[yy], t1[xx], v].astype(F)
+    l12 = luts[t1[yy], t2[xx], v].astype(F)
+    l21 = luts[t2[yy], t1[xx], v].astype(F)
+    l22 = luts[t2[yy], t2[xx], v].astype(F)
+    xa, xa1, ya, ya1 = wa[xx], wa1[xx], wa[yy], wa1[yy]
+    top = ((l11 * xa1).astype(F) + (l12 * xa).astype(F)).astype(F)
+    bot = ((l21 * xa1).astype(F) + (l22 * xa).astype(F)).astype(F)
+    res = ((top * ya1).astype(F) + (bot * ya).astype(F)).astype(F)
+    return np.clip(np.rint(res), 0, 255).astype(np.uint8)
+
+
+def clahe_rgb(img: np.ndarray, limit: int, tabs=None) -> np.ndarray:
+    tabs = tabs or color_tables()
+    lab = rgb_to_lab_u8(img, tabs)
+    lab[..., 0] = clahe_u8(np.ascontiguousarray(lab[..., 0]), limit)
+    return lab_to_rgb_u8(lab, tabs)

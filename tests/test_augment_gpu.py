@@ -41,6 +41,8 @@ DRAWS = [
     dict(photo=3, k=3), dict(photo=3, k=5), dict(A_d4=2, rot=-61.0, photo=3, k=5),
     dict(noise=math.sqrt(10.0), seed=1), dict(noise=math.sqrt(50.0), seed=4_000_000_000),
     dict(A_d4=5, rot=77.0, photo=1, alpha=0.9, beta=0.1, noise=5.0, seed=99), dict(A_d4=1, rot=-15.0, photo=3, k=3, noise=6.5, seed=3),
+    dict(photo=2, clip=1.0), dict(photo=2, clip=2.0), dict(photo=2, clip=40.0), dict(A_d4=6, rot=33.0, photo=2, clip=1.37),
+    dict(A_d4=1, photo=2, clip=1.9, noise=6.0, seed=17),
 ]
 
 
@@ -51,7 +53,8 @@ def _draw(spec):
         a = math.radians(spec["rot"])
         d.update(rotate=1, cos_a=math.cos(a), sin_a=math.sin(a))
     if "photo" in spec:
-        d.update(photo=spec["photo"], alpha=spec.get("alpha", 1.0), beta=spec.get("beta", 0.0), blur_ksize=spec.get("k", 3))
+        d.update(photo=spec["photo"], alpha=spec.get("alpha", 1.0), beta=spec.get("beta", 0.0), blur_ksize=spec.get("k", 3),
+                 clahe_clip=spec.get("clip", 1.0))
     if "noise" in spec:
         d.update(noise_scale=spec["noise"] / 65536.0, noise_seed=spec["seed"])
     return d
@@ -108,7 +111,9 @@ def test_full_size_batch_with_sampled_draws():
     x, y, _ = ds.batch(idx, draws=draws)
     assert torch.isfinite(x).all() and set(torch.unique(y).tolist()) <= {0.0, 1.0}
     sq = [_oracle_letterbox(*r, 512) for r in raws]
-    for j in (0, 5, 13, 31):
+    clahe = [j for j, d in enumerate(draws) if d["photo"] == 2]
+    assert len(clahe) >= 3                                                   # the sampler's OneOf does draw CLAHE
+    for j in sorted({0, 5, 13, 31, *clahe[:3]}):
         xo, yo = A.augment(*sq[idx[j]], draws[j])
         assert np.array_equal(x[j].cpu().numpy(), xo) and np.array_equal(y[j].cpu().numpy(), yo), (j, draws[j])
     # loader protocol: (x, y, names) like DataLoader(VickersDataset) (train.py:423)
@@ -118,9 +123,18 @@ def test_full_size_batch_with_sampled_draws():
 
 def test_argument_errors(dataset):
     _, ds = dataset
-    bad = dict(vk.augment.IDENTITY, photo=2)                     # CLAHE: refused, never silently skipped
-    with pytest.raises(vk.VkError, match="CLAHE"):
-        ds.batch([0], draws=[bad])
+    with pytest.raises(vk.VkError, match="photo"):
+        ds.batch([0], draws=[dict(vk.augment.IDENTITY, photo=4)])
+    L = vk._lib
+    arr = vk.augment._params_array([dict(vk.augment.IDENTITY, photo=2)], 96)
+    x, y = torch.empty(1, 3, 96, 96, device=DEV), torch.empty(1, 1, 96, 96, device=DEV)
+    idx, pdev = torch.zeros(1, dtype=torch.int32, device=DEV), torch.empty(256, dtype=torch.uint8, device=DEV)
+    rc = L.lib().vk_augment_batch(1, 96, 4, ds.images.data_ptr(), ds.masks.data_ptr(), idx.data_ptr(), arr, pdev.data_ptr(), None, None, 0,
+                                  x.data_ptr(), y.data_ptr(), L.current_stream())
+    assert rc != 0 and "CLAHE" in L.lib().vk_last_error_string().decode()                 # CLAHE without tables / workspace: refused, never silently skipped
+    odd = vk.DeviceDataset([np.zeros((20, 20, 3), np.uint8)], [np.zeros((20, 20), np.uint8)], img_size=20, device=DEV)
+    with pytest.raises(vk.VkError, match="size % 8"):
+        odd.batch([0], draws=[dict(vk.augment.IDENTITY, photo=2)])
     with pytest.raises(vk.VkError):
         ds.batch([0], draws=[dict(vk.augment.IDENTITY, photo=3, blur_ksize=4)])
     with pytest.raises(vk.VkError):

@@ -1,7 +1,7 @@
 """Timing of the two SURVEY 8(f) rank 3/4 device components with inputs resident in HBM (HIP events on the launch stream):
 
     geometry   vk_geom_minarearect (threshold -> open/close -> 8-connected components -> hull -> min-area rectangle -> diagonals)
-    augment    vk_augment_batch (flip / rot90 / rotate / brightness-contrast / blur / noise / normalise, one fused pass)
+    augment    vk_augment_batch (flip / rot90 / rotate / brightness-contrast / CLAHE / blur / noise / normalise; one fused pass + a tile-histogram pass for CLAHE samples)
 
     python tools/geom_aug_bench.py            (run through rocprofv3 --kernel-trace --stats for per-kernel numbers)"""
 import importlib
@@ -70,7 +70,7 @@ def main():
         torch.cuda.synchronize()
         host_ms = (time.perf_counter() - t0) * 1e3
         mb = B * h * w * 5 / 1e6
-        print(f"  B={B:3d} {h}x{w}: {us:9.1f} us = {us / B:8.1f} us/map ({mb / us * 1e-3 * 1e3:7.1f} GB/s of 5 algorithmic B/px); "
+        print(f"  B={B:3d} {h}x{w}: {us:9.1f} us = {us / B:8.1f} us/map ({mb / us * 1e3:7.1f} GB/s of 5 algorithmic B/px); "
               f"host mirror incl. allocation + read-back {host_ms:7.2f} ms; components kept: {[len(d) for d in det][:4]}")
     print("== augmentation (train.py:67-113), one fused launch per batch")
     rng = np.random.default_rng(1)
@@ -84,7 +84,9 @@ def main():
     for n in (8, 32, 128):
         idx = [i % 4 for i in range(n)]
         draws = [sm.sample() for _ in range(n)]
-        arr = vk.augment._params_array(draws)
+        arr = vk.augment._params_array(draws, 512)
+        ws = torch.empty(int(lib.vk_augment_workspace_bytes(n, 512)), dtype=torch.uint8, device=dev)
+        n_clahe = sum(1 for d in draws if d["photo"] == 2)
         index = torch.tensor(idx, dtype=torch.int32, device=dev)
         x = torch.empty(n, 3, 512, 512, device=dev)
         y = torch.empty(n, 1, 512, 512, device=dev)
@@ -92,7 +94,7 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
 
         def run():
-            L.check(lib.vk_augment_batch(n, 512, 4, ds.images.data_ptr(), ds.masks.data_ptr(), index.data_ptr(), arr, pdev.data_ptr(), x.data_ptr(), y.data_ptr(), st))
+            L.check(lib.vk_augment_batch(n, 512, 4, ds.images.data_ptr(), ds.masks.data_ptr(), index.data_ptr(), arr, pdev.data_ptr(), ds._tables.data_ptr(), ws.data_ptr(), ws.numel(), x.data_ptr(), y.data_ptr(), st))
         us = timed(run)
         t0 = time.perf_counter()
         for _ in range(10):
@@ -100,7 +102,7 @@ def main():
         torch.cuda.synchronize()
         host_us = (time.perf_counter() - t0) / 10 * 1e6
         by = n * 512 * 512 * 20.0
-        print(f"  n={n:3d}: {us:8.1f} us/batch = {n / us * 1e6:10.0f} img/s ({by / us * 1e-3:6.0f} GB/s of 20 algorithmic B/px: 4 read + 16 written); "
+        print(f"  n={n:3d} ({n_clahe} CLAHE): {us:8.1f} us/batch = {n / us * 1e6:10.0f} img/s ({by / us * 1e-3:6.0f} GB/s of 20 algorithmic B/px: 4 read + 16 written); "
               f"through DeviceDataset.batch incl. host sampling {host_us:8.1f} us/batch")
 
 

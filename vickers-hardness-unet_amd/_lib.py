@@ -54,7 +54,7 @@ class vk_geom_det(C.Structure):
 class vk_aug_params(C.Structure):
     _fields_ = [("d4", C.c_int), ("rotate", C.c_int), ("cos_a", C.c_float), ("sin_a", C.c_float), ("photo", C.c_int),
                 ("alpha", C.c_float), ("beta", C.c_float), ("blur_ksize", C.c_int), ("noise_scale", C.c_float),
-                ("noise_seed", C.c_uint32)]
+                ("noise_seed", C.c_uint32), ("clahe_limit", C.c_int)]
 
 
 class vk_unet_config(C.Structure):
@@ -95,7 +95,8 @@ SIGNATURES = {
     "vk_geom_minarearect": (ci, [P(vk_geom_desc), ci, vp, vp, vp, vp, vp, sz, vp]),
     "vk_letterbox_u8": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
     "vk_letterbox_mask_u8": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
-    "vk_augment_batch": (ci, [ci, ci, ci, vp, vp, vp, P(vk_aug_params), vp, vp, vp, vp]),
+    "vk_augment_workspace_bytes": (C.c_size_t, [ci, ci]),
+    "vk_augment_batch": (ci, [ci, ci, ci, vp, vp, vp, P(vk_aug_params), vp, vp, vp, C.c_size_t, vp, vp, vp]),
     "vk_input_transform": (ci, [ci, ci, ci, ci, vp, vp, vp]),
     "vk_bn_finalize": (ci, [ci, ci, vp, cd, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
     "vk_bn_relu_maxpool": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),

@@ -9,12 +9,16 @@
 //   vk_augment_batch : per step — for each of the n samples, with draws made on the host (vk_aug_params):
 //        OneOf(HorizontalFlip, VerticalFlip, RandomRotate90)   train.py:81-85   exact pixel permutation, folded into the tap fetch
 //        Rotate(limit=180, BORDER_CONSTANT)                    train.py:89      inverse-mapped bilinear (image) / nearest (mask) gather
-//        OneOf(RandomBrightnessContrast, [CLAHE], GaussianBlur) train.py:96-100 LUT arithmetic / exact binomial 3x3, 5x5 blur
+//        OneOf(RandomBrightnessContrast, CLAHE, GaussianBlur)  train.py:96-100 LUT arithmetic / tile-histogram equalisation of L / binomial blur
 //        GaussNoise                                            train.py:104     counter-based hash -> Irwin-Hall normal deviate
 //        Normalize + ToTensorV2                                train.py:108-112 float32 [3][S][S], mask float32 [1][S][S]
 //      in ONE pass: 64 x 4 pixel tiles; the geometric result of the tile (+ a 2-pixel apron when the sample is blurred) is
 //      staged in LDS as uint8, everything after it is per-pixel.  HBM-bound byte work: ~3-12 source bytes read (L2-resident
 //      neighbours) and 16 bytes written per pixel; no MFMA.
+//      CLAHE is the one transform that needs the whole image before any pixel: samples that drew it get one extra pass first
+//      (k_clahe_tiles: one workgroup per 8 x 8 tile — geometric stage, RGB -> L*a*b* in integer fixed point, 256-bin histogram
+//      in LDS, OpenCV's clip / redistribute / cdf -> tile LUT), and k_augment interpolates the four neighbouring LUTs and goes
+//      back to RGB.
 // Arithmetic follows oracle/augment_oracle.py operation by operation (contraction off): outputs are bit-identical to it.
 #include <stdlib.h>
 
@@ -32,6 +36,7 @@ struct AugParams {      // = vk_aug_params
   int blur_ksize;
   float noise_scale;
   uint32_t noise_seed;
+  int clahe_limit;
 };
 static_assert(sizeof(AugParams) == sizeof(vk_aug_params), "vk_aug_params layout");
 
@@ -116,8 +121,124 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 
 constexpr int AUG_TW = 64, AUG_TH = 4, AUG_R = 2;       // tile and blur apron
 
+// ---- CLAHE (train.py:98): 8-bit RGB <-> L*a*b* in integer fixed point (oracle/augment_oracle.py: rgb_to_lab_u8 / lab_to_rgb_u8)
+constexpr int TAB_LIN = 0, TAB_FT = 256, TAB_ENC = 256 + 4097;
+static_assert(TAB_ENC + 4097 == VK_AUG_TABLE_INTS, "colour table layout");
+
+__device__ __forceinline__ long long floordiv(long long a, long long b) {      // b > 0; Python's //
+  long long q = a / b;
+  return (a % b < 0) ? q - 1 : q;
+}
+__device__ __forceinline__ int clampi(long long v, int lo, int hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); }
+
+__device__ __forceinline__ void rgb_to_lab(const int* __restrict__ tab, int r, int g, int b, int& L, int& A, int& B) {
+  const int lr = tab[TAB_LIN + r], lg = tab[TAB_LIN + g], lb = tab[TAB_LIN + b];
+  const int tx = clampi((1777 * lr + 1541 * lg + 778 * lb + 2048) >> 12, 0, 4096);
+  const int ty = clampi((871 * lr + 2929 * lg + 296 * lb + 2048) >> 12, 0, 4096);
+  const int tz = clampi((73 * lr + 448 * lg + 3575 * lb + 2048) >> 12, 0, 4096);
+  const long long fx = tab[TAB_FT + tx], fy = tab[TAB_FT + ty], fz = tab[TAB_FT + tz];
+  L = clampi(floordiv(116ll * fy * 255 - 16ll * 255 * 32768 + 50ll * 32768, 100ll * 32768), 0, 255);
+  A = clampi(((500 * (fx - fy) + 16384) >> 15) + 128, 0, 255);
+  B = clampi(((200 * (fy - fz) + 16384) >> 15) + 128, 0, 255);
+}
+
+__device__ __forceinline__ int lab_finv(long long f) {                           // t x 4096 from f x 32768
+  const long long cube = (f * f * f + (1ll << 32)) >> 33;
+  const long long low = floordiv((f * 116 - 16ll * 32768) * 27 * 4096 + (24389ll * 32768) / 2, 24389ll * 32768);
+  return clampi(f > 6780 ? cube : low, 0, 8192);
+}
+
+__device__ __forceinline__ void lab_to_rgb(const int* __restrict__ tab, int L, int A, int B, int& r, int& g, int& b) {
+  const long long fy = ((long long)(L * 100 * 32768 + 127) / 255 + 16 * 32768 + 58) / 116;
+  const long long fx = fy + floordiv((long long)(A - 128) * 32768 + 250, 500);
+  const long long fz = fy - floordiv((long long)(B - 128) * 32768 + 100, 200);
+  const long long tx = lab_finv(fx), ty = lab_finv(fy), tz = lab_finv(fz);
+  r = tab[TAB_ENC + clampi((12615 * tx - 6296 * ty - 2223 * tz + 2048) >> 12, 0, 4096)];
+  g = tab[TAB_ENC + clampi((-3773 * tx + 7684 * ty + 185 * tz + 2048) >> 12, 0, 4096)];
+  b = tab[TAB_ENC + clampi((217 * tx - 836 * ty + 4715 * tz + 2048) >> 12, 0, 4096)];
+}
+
+// One workgroup per (tile, CLAHE sample): geometric stage -> L, a, b, mask of the tile's pixels into the workspace, 256-bin
+// histogram of L in LDS, then OpenCV's clahe.cpp per-tile LUT (clip at `limit`, excess / 256 to every bin + the residual to every
+// (256 / residual)-th bin, lut = cvRound(cdf * 255 / tileArea) in float32).  grid (8, 8, n); samples without CLAHE leave at once.
+__global__ __launch_bounds__(256) void k_clahe_tiles(int S, int n_items, const uint8_t* __restrict__ images, const uint8_t* __restrict__ masks,
+                                                     const int* __restrict__ index, const AugParams* __restrict__ params,
+                                                     const int* __restrict__ tab, uint8_t* __restrict__ ws) {
+#pragma clang fp contract(off)
+  const int n = blockIdx.z;
+  const AugParams p = params[n];
+  if (p.photo != 2) return;
+  __shared__ int hist[256];
+  __shared__ int scan[256];
+  const int item = min(max(index[n], 0), n_items - 1);
+  const uint8_t* img = images + (size_t)item * S * S * 3;
+  const uint8_t* msk = masks + (size_t)item * S * S;
+  const size_t per = (size_t)S * S * 4 + 64 * 256;
+  uint32_t* lab = (uint32_t*)(ws + (size_t)n * per);
+  uint8_t* lut = ws + (size_t)n * per + (size_t)S * S * 4 + (size_t)(blockIdx.y * 8 + blockIdx.x) * 256;
+  const int ts = S >> 3, y0 = blockIdx.y * ts, x0 = blockIdx.x * ts;
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < ts * ts; i += 256) {
+    const int ly = i / ts, lx = i - ly * ts;
+    const Px q = aug_geom(p, S, img, msk, y0 + ly, x0 + lx);
+    int L, A, B;
+    rgb_to_lab(tab, q.r, q.g, q.b, L, A, B);
+    lab[(size_t)(y0 + ly) * S + x0 + lx] = (uint32_t)L | ((uint32_t)A << 8) | ((uint32_t)B << 16) | ((uint32_t)q.m << 24);
+    atomicAdd(&hist[L], 1);
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  int h = hist[t];
+  const int limit = p.clahe_limit;
+  scan[t] = max(h - limit, 0);
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) scan[t] += scan[t + off];
+    __syncthreads();
+  }
+  const int clipped = scan[0];
+  __syncthreads();
+  h = min(h, limit) + (clipped >> 8);
+  const int residual = clipped & 255;
+  if (residual) {
+    const int step = max(256 / residual, 1);
+    if (t % step == 0 && t / step < residual) ++h;
+  }
+  scan[t] = h;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {                // inclusive scan (integers: order-free)
+    const int v = t >= off ? scan[t - off] : 0;
+    __syncthreads();
+    scan[t] += v;
+    __syncthreads();
+  }
+  const float scale = 255.f / (float)(ts * ts);
+  lut[t] = (uint8_t)min(max((int)rintf((float)scan[t] * scale), 0), 255);
+}
+
+// the four-LUT interpolation of clahe.cpp for pixel (y, x) with value v: tile coordinates x / tileW - 0.5, float32, fixed order
+__device__ __forceinline__ int clahe_interp(const uint8_t* __restrict__ lut, int S, int y, int x, int v) {
+#pragma clang fp contract(off)
+  const float inv = 1.f / (float)(S >> 3);
+  const float txf = (float)x * inv - 0.5f, tyf = (float)y * inv - 0.5f;
+  const float tx1f = floorf(txf), ty1f = floorf(tyf);
+  const float xa = txf - tx1f, ya = tyf - ty1f;
+  const float xa1 = 1.f - xa, ya1 = 1.f - ya;
+  int tx1 = (int)tx1f, ty1 = (int)ty1f;
+  const int tx2 = min(tx1 + 1, 7), ty2 = min(ty1 + 1, 7);
+  tx1 = max(tx1, 0); ty1 = max(ty1, 0);
+  const float l11 = (float)lut[(ty1 * 8 + tx1) * 256 + v], l12 = (float)lut[(ty1 * 8 + tx2) * 256 + v];
+  const float l21 = (float)lut[(ty2 * 8 + tx1) * 256 + v], l22 = (float)lut[(ty2 * 8 + tx2) * 256 + v];
+  const float top = l11 * xa1 + l12 * xa;
+  const float bot = l21 * xa1 + l22 * xa;
+  const float res = top * ya1 + bot * ya;
+  return min(max((int)rintf(res), 0), 255);
+}
+
 __global__ __launch_bounds__(256) void k_augment(int S, int n_items, const uint8_t* __restrict__ images, const uint8_t* __restrict__ masks,
-                                                 const int* __restrict__ index, const AugParams* __restrict__ params, float* __restrict__ xo,
+                                                 const int* __restrict__ index, const AugParams* __restrict__ params,
+                                                 const int* __restrict__ tab, const uint8_t* __restrict__ ws, float* __restrict__ xo,
                                                  float* __restrict__ yo) {
 #pragma clang fp contract(off)
   const int n = blockIdx.z;
@@ -162,6 +283,14 @@ __global__ __launch_bounds__(256) void k_augment(int S, int n_items, const uint8
     const int tot = k == 3 ? 16 : 256;
     r = (acc[0] + tot / 2) / tot; g = (acc[1] + tot / 2) / tot; b = (acc[2] + tot / 2) / tot;
     m = tile[ty + AUG_R][tx + AUG_R][3];
+  } else if (p.photo == 2) {
+    // CLAHE: k_clahe_tiles left L, a, b, mask of the geometric result and the 64 tile LUTs of this sample in the workspace
+    if (!in) return;
+    const size_t per = (size_t)S * S * 4 + 64 * 256;
+    const uint32_t q = ((const uint32_t*)(ws + (size_t)n * per))[(size_t)y * S + x];
+    const int L = clahe_interp(ws + (size_t)n * per + (size_t)S * S * 4, S, y, x, (int)(q & 255));
+    lab_to_rgb(tab, L, (int)((q >> 8) & 255), (int)((q >> 16) & 255), r, g, b);
+    m = (int)(q >> 24);
   } else {
     if (!in) return;
     const Px q = aug_geom(p, S, img, msk, y, x);
@@ -309,23 +438,43 @@ extern "C" int vk_letterbox_mask_u8(const vk_letterbox_desc* d, const uint8_t* m
   return VK_OK;
 }
 
+extern "C" size_t vk_augment_workspace_bytes(int n, int size) {
+  if (n < 1 || size < 8) return 0;
+  return (size_t)n * ((size_t)size * size * 4 + 64 * 256);
+}
+
 extern "C" int vk_augment_batch(int n, int size, int n_items, const uint8_t* images_rgb, const uint8_t* masks, const int* index_dev,
-                                const vk_aug_params* params_host, void* params_dev, float* x, float* y, void* stream) {
+                                const vk_aug_params* params_host, void* params_dev, const int* color_tables, void* workspace,
+                                size_t workspace_bytes, float* x, float* y, void* stream) {
   VK_CHECK_ARG(n >= 1 && n <= 65535 && size >= 8 && size <= 16384 && n_items >= 1, "vk_augment_batch: bad batch / size / item count");
   VK_CHECK_ARG(images_rgb && masks && index_dev && params_host && params_dev && x && y, "vk_augment_batch: null buffer");
+  int n_clahe = 0;
   for (int i = 0; i < n; ++i) {
     const vk_aug_params& p = params_host[i];
     VK_CHECK_ARG(p.d4 >= 0 && p.d4 <= 6, "vk_augment_batch: sample %d: d4 %d outside 0..6", i, p.d4);
-    VK_CHECK_ARG(p.photo == 0 || p.photo == 1 || p.photo == 3, "vk_augment_batch: sample %d: photo %d (2 = CLAHE is not implemented on the device)", i, p.photo);
+    VK_CHECK_ARG(p.photo >= 0 && p.photo <= 3, "vk_augment_batch: sample %d: photo %d outside 0..3", i, p.photo);
+    if (p.photo == 2) {
+      ++n_clahe;
+      VK_CHECK_ARG(p.clahe_limit >= 1, "vk_augment_batch: sample %d: clahe_limit %d must be >= 1", i, p.clahe_limit);
+    }
     VK_CHECK_ARG(p.photo != 3 || p.blur_ksize == 3 || p.blur_ksize == 5, "vk_augment_batch: sample %d: blur_ksize %d must be 3 or 5", i, p.blur_ksize);
     VK_CHECK_ARG(!p.rotate || fabsf(p.cos_a * p.cos_a + p.sin_a * p.sin_a - 1.f) < 1e-3f, "vk_augment_batch: sample %d: (cos, sin) not a rotation", i);
     VK_CHECK_ARG(p.noise_scale >= 0.f && p.noise_scale < 1.f, "vk_augment_batch: sample %d: noise_scale %g", i, (double)p.noise_scale);
   }
+  if (n_clahe) {
+    VK_CHECK_ARG(size % 8 == 0, "vk_augment_batch: CLAHE needs size %% 8 == 0 (8 x 8 tiles), got %d", size);
+    VK_CHECK_ARG(color_tables && workspace, "vk_augment_batch: %d sample(s) draw CLAHE but color_tables / workspace is null", n_clahe);
+    VK_CHECK_ARG(workspace_bytes >= vk_augment_workspace_bytes(n, size), "vk_augment_batch: workspace of %zu bytes, need %zu", workspace_bytes,
+                 vk_augment_workspace_bytes(n, size));
+  }
   hipStream_t st = (hipStream_t)stream;
   VK_CHECK_HIP(hipMemcpyAsync(params_dev, params_host, (size_t)n * sizeof(vk_aug_params), hipMemcpyHostToDevice, st));
-  vkh::ProfScope ps("augment", st, 0.0, (double)n * size * size * (4.0 + 16.0));
+  vkh::ProfScope ps("augment", st, 0.0, (double)n * size * size * (4.0 + 16.0) + (double)n_clahe * size * size * (4.0 + 4.0 + 4.0));
+  if (n_clahe)
+    hipLaunchKernelGGL(k_clahe_tiles, dim3(8, 8, n), dim3(256), 0, st, size, n_items, images_rgb, masks, index_dev, (const AugParams*)params_dev,
+                       color_tables, (uint8_t*)workspace);
   hipLaunchKernelGGL(k_augment, dim3((size + AUG_TW - 1) / AUG_TW, (size + AUG_TH - 1) / AUG_TH, n), dim3(256), 0, st, size, n_items, images_rgb, masks,
-                     index_dev, (const AugParams*)params_dev, x, y);
+                     index_dev, (const AugParams*)params_dev, color_tables, (const uint8_t*)workspace, x, y);
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }
