@@ -99,16 +99,22 @@ def conv_run(d, w, y, y1=None, split=0, acc=0, stats=None, plain=False):
     return packed
 
 
-@pytest.fixture(params=["tile", "tile_alt1", "tile_alt2", "tile_alt3", "tile_alt7", "tile_alt8", "tile_persist", "tap"])
+@pytest.fixture(params=["tile", "tile_alt1", "tile_alt2", "tile_alt3", "tile_alt7", "tile_alt8", "tile_alt2_plain", "tile_alt7_plain",
+                        "tile_persist", "tap"])
 def conv_path(request, monkeypatch):
-    """tile: 3x3 stride-1 tile kernels with halo-pack weights (alt1/2/3/7/8: each tile shape of the K >= 128 class forced);
+    """tile: 3x3 stride-1 tile kernels with halo-pack weights (alt1/2/3/7/8: each tile shape of the K >= 128 class forced; the
+    8-wave shapes 2 and 7 run the software-pipelined kernel by default, `_plain` = their plain stage loop, VK_COL_PIPE=0);
     tile_persist: the persistent form of the K < 128 tile kernels forced onto the small test shapes, THREE workgroups walking all
     tiles (next tile's halo prefetched under the current tile's last stage and epilogue);
     tap: the tap-by-tap implicit-GEMM kernel with plain weights."""
     if request.param.startswith("tile_alt"):
-        monkeypatch.setenv("VK_COL_ALT", request.param[-1])
+        monkeypatch.setenv("VK_COL_ALT", request.param[8])
     else:
         monkeypatch.delenv("VK_COL_ALT", raising=False)
+    if request.param.endswith("_plain"):
+        monkeypatch.setenv("VK_COL_PIPE", "0")
+    else:
+        monkeypatch.delenv("VK_COL_PIPE", raising=False)
     if request.param == "tile_persist":
         monkeypatch.setenv("VK_COL_PERSIST", "2")
         monkeypatch.setenv("VK_COL_PERSIST_GRID", "3")
@@ -140,6 +146,9 @@ CONV_CASES = [
     # name, N, H, C, K, R, stride, pad, affine
     ("l1_3x3", 2, 24, 64, 64, 3, 1, 1, True),
     ("l2_s2", 2, 24, 64, 128, 3, 2, 1, False),
+    ("l3_s2_affine", 2, 20, 128, 256, 3, 2, 1, True),
+    ("l4_s2_ragged", 1, 18, 256, 512, 3, 2, 1, False),
+    ("s2_wide", 1, 70, 64, 128, 3, 2, 1, False),
     ("l2_down1x1", 2, 24, 64, 128, 1, 2, 0, False),
     ("l4_3x3", 1, 8, 512, 512, 3, 1, 1, True),
     ("dec3_c2", 1, 40, 32, 32, 3, 1, 1, True),
@@ -309,6 +318,8 @@ DGRAD_CASES = [
     ("s2_3x3", 2, 24, 64, 128, 3, 2, 1),
     ("s2_3x3_parity_tiles", 2, 32, 64, 128, 3, 2, 1),      # 16x16 pixels per parity class = whole 128-pixel tiles: tap skipping active
     ("s2_3x3_c256", 1, 64, 128, 256, 3, 2, 1),
+    ("s2_3x3_ragged", 1, 26, 256, 512, 3, 2, 1),           # 13 x 13 dz: partial 8 x 16 tiles in both directions
+    ("s2_3x3_wide", 1, 72, 64, 128, 3, 2, 1),              # three tile columns
     ("s2_1x1", 2, 24, 64, 128, 1, 2, 0),
     ("s2_1x1_parity_tiles", 2, 32, 64, 128, 1, 2, 0),
     ("k16", 1, 40, 32, 16, 3, 1, 1),      # reduction over 16 output channels (small-C mode)

@@ -44,7 +44,8 @@ struct HaloParams {
   void* y1;
   int ld0, ld1, split;
   double* stats;
-  int N, H, W, K, C, flip, accumulate, pool2;
+  int N, H, W, K, C, flip, accumulate, pool2;      // H, W: OUTPUT size (= input size for the stride-1 kernels)
+  int Hi, Wi;                                       // input size (stride-2 forward: 2 * H, 2 * W)
   int tiles_x, tiles_y, nchunks;
   // fused BatchNorm+ReLU backward reduce on the first output part: g = y * [z*scale+shift > 0] is stored instead of y and
   // sum(g), sum(g*z) go to bnr_sums [VK_STATS_REPLICAS][2][ld0]
@@ -99,9 +100,10 @@ __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 //   * optional channel split (concat gradient): channels >= split go to y1
 //   * optional pool2: the FIRST output part is summed over 2x2 pixel groups and written at half resolution
 //     (nearest-x2 upsample backward fused into the data gradient; the full-resolution tensor never exists)
-template <typename T, int TH, int BN, int TP, int TC, int NT = 256, bool PRE = false>
+//   * OS = 2 (stride-2 data gradient): tile pixel (row, col) is output pixel (2 (y0 + row) + py, 2 (x0 + col) + px)
+template <typename T, int TH, int BN, int TP, int TC, int NT = 256, bool PRE = false, int OS = 1>
 __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP], const HaloParams& p, int n, int y0, int x0, int n0,
-                                              int wrow0, int wch0) {
+                                              int wrow0, int wch0, int py = 0, int px = 0) {
   using Tr = ElemTraits<T>;
   constexpr int EB = Tr::kBytes, VE = Tr::kVec;
   constexpr int BM = TH * 16;
@@ -203,7 +205,7 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
 #pragma unroll
       for (int ps = 0; ps < (PRE ? EPASS : 0); ++ps) {
         const int row = e_row + ps * ERPP;
-        const int y = y0 + (row >> 4), x = x0 + (row & 15);
+        const int y = OS * (y0 + (row >> 4)) + py, x = OS * (x0 + (row & 15)) + px;
         oldv[ps] = u32x4_t{0, 0, 0, 0};
         zv[ps] = u32x4_t{0, 0, 0, 0};
         if (y < p.H && x < p.W && col_ok) {
@@ -216,7 +218,7 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
 #pragma unroll
     for (int ps = 0; ps < EPASS; ++ps) {
       const int row = e_row + ps * ERPP;          // tile pixel index
-      const int y = y0 + (row >> 4), x = x0 + (row & 15);
+      const int y = OS * (y0 + (row >> 4)) + py, x = OS * (x0 + (row & 15)) + px;
       if (y < p.H && x < p.W && col_ok) {
         const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(smem + row * ESB + e_vec * 16);
         const size_t eoff = (((size_t)n * p.H + y) * p.W + x) * ld + colx;
@@ -519,37 +521,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
 //     traffic (L2 -> LDS) of the 4-wave 8x16x128 tile.
 //   * ADB: the halo image is double buffered (next chunk written during stage 1, no extra barrier); otherwise it is written
 //     after an extra barrier in stage 2 (less LDS -> two workgroups per CU).
-template <typename T, int TH, int BN, int WGM, int WGN, bool ADB>
+//   * STR = 2 (the three stride-2 3x3 convolutions that open layers 2-4, forward): the (2 TH + 1) x 33 input pixels under a TH x 16
+//     output tile are staged with the odd and the even input columns in separate planes of every LDS row (slot = row * 34 +
+//     (x & 1) * 17 + (x >> 1)), so that output pixel li of tap column s still reads slot li + const: the fragment reads keep the
+//     conflict-free 96-byte stride of the stride-1 image; tile row b of filter row r reads halo row 2 b + r.
+template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int STR = 1>
 struct ColCfg {
   using Tr = ElemTraits<T>;
   static constexpr int EB = Tr::kBytes;
   static constexpr int VE = Tr::kVec;
   static constexpr int CK = 64 / EB;
   static constexpr int NW = WGM * WGN, NT = 64 * NW;
-  static constexpr int HH = TH + 2, HPIX = HH * 18;
+  static constexpr int HH = STR == 1 ? TH + 2 : 2 * TH + 1;         // staged input rows
+  static constexpr int HWI = STR == 1 ? 18 : 33;                    // staged input columns
+  static constexpr int RS = STR == 1 ? 18 : 34;                     // LDS slots per row
+  static constexpr int HPIX = HH * HWI;
   static constexpr int APS = 96;
-  static constexpr int A_BYTES = HPIX * APS;
+  static constexpr int A_BYTES = HH * RS * APS;
   static constexpr int NA = ADB ? 2 : 1;
   static constexpr int B_BYTES = 3 * BN * 64;
   static constexpr int NPV = (HPIX * 4 + NT - 1) / NT;
   static constexpr int NPIECE = 3 * BN / 16;           // 1-KiB LDS-DMA pieces per stage
   static constexpr int BM = TH * 16;
   static constexpr int TP = TH / WGM, TC = BN / WGN / 16;
+  static constexpr int NX = STR * (TP - 1) + 3;                     // halo rows a wave reads per stage
   static constexpr int ESB = BN * EB + 16;
   static constexpr int MAIN = NA * A_BYTES + 2 * B_BYTES;
   static constexpr int ESLOTS = (BN / VE > 16) ? NW * 4 / (BN / VE / 16) : NW * 4;
   static constexpr int EPI = BM * ESB + ESLOTS * BN * 2 * 4;     // + [wave x 16-lane row][channel][2] partial sums
   static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
   static_assert(TH % WGM == 0 && BN % (16 * WGN) == 0 && (NW == 4 || NW == 8), "wave layout");
+  static_assert(STR == 1 || STR == 2, "stride");
   static_assert(SMEM <= 160 * 1024, "main-loop / epilogue LDS image exceeds the 160 KiB of a CU");
   static_assert(EPI >= BM * ESB + ESLOTS * BN * 8, "epilogue partial-sum slots must fit behind the output tile");
 };
 
-template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW>
+template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW, int STR = 1>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const HaloParams p) {
-  using Cfg = ColCfg<T, TH, BN, WGM, WGN, ADB>;
+  using Cfg = ColCfg<T, TH, BN, WGM, WGN, ADB, STR>;
   constexpr int EB = Cfg::EB, VE = Cfg::VE, CK = Cfg::CK, HPIX = Cfg::HPIX, NPV = Cfg::NPV, NT = Cfg::NT, NW = Cfg::NW;
-  constexpr int TP = Cfg::TP, TC = Cfg::TC, APS = Cfg::APS, NPIECE = Cfg::NPIECE;
+  constexpr int TP = Cfg::TP, TC = Cfg::TC, APS = Cfg::APS, NPIECE = Cfg::NPIECE, RS = Cfg::RS, HWI = Cfg::HWI, NX = Cfg::NX;
   typedef __attribute__((address_space(3))) void lds_void;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -569,6 +580,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
     const int j = bt >> 3;
     ky = j % p.kyn;
     bt = (bt & 7) * (int)((gridDim.x / p.kyn) >> 3) + j / p.kyn;
+  } else if (p.kyn < 0) {
+    // weights-stationary placement: XCD x runs channel tile x % kn only, so its L2 holds 1 / kn of the layer's weights (the
+    // stream every workgroup re-reads, 3-5 MB per layer on the K >= 256 layers against 4 MB of L2) and the pixel tiles' halos
+    // are fetched by kn XCDs instead of one
+    const int kn = -p.kyn, xcd = bt & 7;
+    ky = xcd % kn;
+    bt = (xcd / kn) * (int)(gridDim.x >> 3) + (bt >> 3);
   } else if ((gridDim.x & 7) == 0) {
     bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);
   }
@@ -584,6 +602,420 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
   const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
 
   // ---- halo staging geometry (as in the row-staged kernel, NT threads)
+  const int hv = tid & 3;
+  int h_full[NPV], h_half[NPV];
+  const int Hh = p.Hi >> 1, Wh = p.Wi >> 1;
+#pragma unroll
+  for (int i = 0; i < NPV; ++i) {
+    const int hp = (tid >> 2) + i * (NT / 4);
+    const int hy = hp / HWI, hx = hp - hy * HWI;
+    const int y = STR * y0 - 1 + hy, x = STR * x0 - 1 + hx;
+    const bool ok = hp < HPIX && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+    h_full[i] = ok ? (n * p.Hi + y) * p.Wi + x : -1;
+    h_half[i] = ok ? (n * Hh + (y >> 1)) * Wh + (x >> 1) : -1;
+  }
+  u32x4_t areg[NPV];
+  float sc[VE], sh[VE];
+  bool aff = false, relu = false;
+
+  auto load_halo = [&](int cc) {
+    const int c = cc * CK;
+    const bool first = c < p.s0.C;
+    const HaloSrc& sd = first ? p.s0 : p.s1;
+    const int cl = (first ? c : c - p.s0.C) + hv * VE;
+    aff = sd.scale != nullptr;
+    relu = sd.relu != 0;
+    if (aff) {
+#pragma unroll
+      for (int j = 0; j < VE; j += 4) {
+        const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(sd.scale + cl + j);
+        const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(sd.shift + cl + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[j + e] = s4[e]; sh[j + e] = h4[e]; }
+      }
+    }
+    const bool up = STR == 1 && sd.up != 0;
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int pix = up ? h_half[i] : h_full[i];
+      const uint32_t off = (uint32_t)(pix * sd.C + cl) * (uint32_t)EB;
+      if (first) areg[i] = buf_load16(rs0, pix >= 0 ? off : kOOB);
+      else areg[i] = buf_load16(rs1, pix >= 0 ? off : kOOB);
+    }
+  };
+  auto store_halo = [&](char* A) {
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int hp = (tid >> 2) + i * (NT / 4);
+      if (hp >= HPIX) continue;
+      u32x4_t v = areg[i];
+      if (aff) {
+        v = AffineRelu<T>::run(v, sc, sh, relu);
+        if (h_full[i] < 0) v = u32x4_t{0, 0, 0, 0};     // zero padding is applied after BN+ReLU
+      }
+      int slot = hp;
+      if (STR == 2) {                                       // odd / even input columns in separate planes of the row
+        const int hy = hp / HWI, hx = hp - hy * HWI;
+        slot = hy * RS + (hx & 1) * 17 + (hx >> 1);
+      }
+      *reinterpret_cast<u32x4_t*>(A + slot * APS + hv * 16) = v;
+    }
+  };
+
+  // weights of stage (chunk cc, filter column s) -> weight buffer `buf`: slot r = tap (r, s); data-gradient mode takes tap 8 - t
+  const uint32_t slab_bytes = (uint32_t)p.K * 64u;         // one (chunk, tap) slab of the halo pack
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto dma_b = [&](int cc, int s, int buf) {
+#pragma unroll
+    for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
+      const int pc = wave + i * NW;                        // wave-uniform
+      if (NPIECE % NW == 0 || pc < NPIECE) {
+        const int r = pc / (BN / 16), sub = pc - r * (BN / 16);
+        const int tap = p.flip ? 8 - (3 * r + s) : 3 * r + s;
+        const uint32_t goff = (uint32_t)(cc * 9 + tap) * slab_bytes + (uint32_t)(n0 + sub * 16) * 64u;
+        char* dst = Bbuf + buf * Cfg::B_BYTES + (r * BN + sub * 16) * 64;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, lane16, goff, 0, 0);
+      }
+    }
+  };
+
+  // ---- accumulators and per-lane fragment bases
+  const int wrow0 = (wave / WGN) * TP;
+  const int wch0 = (wave % WGN) * (TC * 16);
+  f32x4_t acc[TC][TP];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int li = lane & 15, kg = lane >> 4;
+  const int a_lane = (STR * wrow0 * RS + li) * APS + kg * 16;
+  const int b_lane = (wch0 + li) * 64 + ((kg ^ swz(li)) << 4);
+
+  auto compute = [&](const char* A, const char* B) {
+    u32x4_t X[NX], W[3][TC];
+#pragma unroll
+    for (int h = 0; h < NX; ++h) X[h] = *reinterpret_cast<const u32x4_t*>(A + h * (RS * APS));
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int a = 0; a < TC; ++a) W[r][a] = *reinterpret_cast<const u32x4_t*>(B + (r * BN + a * 16) * 64);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = Mma<T>::run(W[r][a], X[STR * b + r], acc[a][b]);
+    // issue order: [halo rows + filter row 0][filter row 1][MFMAs row 0][filter row 2][MFMAs row 1][MFMAs row 2]
+    constexpr int NM = TC * TP * (sizeof(T) == 4 ? 4 : 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, NX + TC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, TC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, TC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+  };
+
+#ifdef VK_STAMP
+  unsigned long long t_begin, t_pro, tk_load = 0, tk_comp = 0, tk_store = 0, tk_bar = 0;
+  VK_T(t_begin)
+#endif
+  // ---- prologue: first chunk's halo + stage 0 weights (split-K: this workgroup's slice of the chunks)
+  const int ksp = p.ksplit > 1 ? p.ksplit : 1;
+  const int c_begin = (int)((long)p.nchunks * blockIdx.z / ksp), c_end = (int)((long)p.nchunks * (blockIdx.z + 1) / ksp);
+  load_halo(c_begin);
+  dma_b(c_begin, 0, 0);
+  store_halo(Abuf);
+  __syncthreads();                                        // also drains the LDS-DMA (vmcnt(0))
+  VK_T(t_pro)
+
+  int st = 0;
+  for (int cc = c_begin; cc < c_end; ++cc) {
+    const bool next_chunk = cc + 1 < c_end;
+    const char* A = Abuf + (ADB ? ((cc - c_begin) & 1) * Cfg::A_BYTES : 0) + a_lane;
+    char* const Anext = Abuf + (ADB ? ((cc - c_begin + 1) & 1) * Cfg::A_BYTES : 0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s, ++st) {
+#ifdef VK_STAMP
+      unsigned long long t0, t1, t2, t3, t4;
+#endif
+      VK_T(t0)
+      // next stage's weights into the other buffer (all waves passed the barrier that closed its last readers)
+      if (!(p.dbg & 2)) {
+        if (s < 2) dma_b(cc, s + 1, (st + 1) & 1);
+        else if (next_chunk) dma_b(cc + 1, 0, (st + 1) & 1);
+      }
+      if (s == 0 && next_chunk && !(p.dbg & 4)) load_halo(cc + 1);
+      VK_T(t1)
+      compute(A + (STR == 1 ? s : (s & 1) * 17 + (s >> 1)) * APS, Bbuf + (st & 1) * Cfg::B_BYTES + b_lane);
+      VK_T(t2)
+      if (ADB) {
+        if (s == 1 && next_chunk && !(p.dbg & 4)) store_halo(Anext);
+      } else {
+        if (s == 2 && next_chunk && !(p.dbg & 4)) {
+          __syncthreads();                                // every wave is done reading this chunk's halo
+          store_halo(Anext);
+        }
+      }
+      VK_T(t3)
+      if (!(p.dbg & 8)) __syncthreads();
+      VK_T(t4)
+#ifdef VK_STAMP
+      tk_load += t1 - t0; tk_comp += t2 - t1; tk_store += t3 - t2; tk_bar += t4 - t3;
+#endif
+    }
+  }
+#ifdef VK_STAMP
+  unsigned long long te0, te1;
+  VK_T(te0)
+#endif
+  if (p.ksplit > 1) {
+    // partial tile straight from the accumulators: lane = pixel li, four consecutive channels per 16-byte store
+    float* sl = p.slab + (size_t)blockIdx.z * ((size_t)p.N * p.H * p.W * p.K);
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) {
+        const int y = y0 + wrow0 + b, x = x0 + li, ch = n0 + wch0 + a * 16 + kg * 4;
+        if (y < p.H && x < p.W && ch < p.K) *reinterpret_cast<f32x4_t*>(sl + (((size_t)n * p.H + y) * p.W + x) * p.K + ch) = acc[a][b];
+      }
+    return;
+  }
+  halo_epilogue<T, TH, BN, TP, TC, NT, (BN <= 64 && TH == 16)>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
+#ifdef VK_STAMP
+  VK_T(te1)
+  if (p.stamps && lane == 0) {
+    unsigned long long* o = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+    o[0] = tk_load; o[1] = tk_comp; o[2] = tk_store; o[3] = tk_bar; o[4] = te1 - te0; o[5] = t_pro - t_begin; o[6] = te1 - t_begin; o[7] = st;
+  }
+#endif
+}
+
+// ---- data gradient of the stride-2 3x3 convolutions (the openers of layers 2-4): dx[y][x] = sum over the taps (r, s) with
+// y + 1 - r and x + 1 - s even of  W[.][r][s]^T dz[(y + 1 - r) / 2][(x + 1 - s) / 2].  The parity class (y & 1, x & 1) of an output
+// pixel selects its taps — (0,0): the centre tap; (0,1), (1,0): two; (1,1): the four corners — so a workgroup stages ONE
+// (TH + 1) x 17 tile of dz per channel chunk and feeds all nine taps from it like the stride-1 kernel, into FOUR accumulator sets
+// (one per class: the 2 TH x 32 output pixels above the tile); tap (r, s) goes to class (r != 1, s != 1) and reads dz at offset
+// (r == 0, s == 0).  No zero-filled operand rows and one staging pass instead of the tap-by-tap gather of the v0 kernel.
+// Weights: the halo pack of the transposed filter ([chunk of K][forward tap][C][32]), taps not flipped.
+template <typename T, int TH, int BN, int WGM, int WGN>
+struct S2dCfg {
+  using Tr = ElemTraits<T>;
+  static constexpr int EB = Tr::kBytes, VE = Tr::kVec, CK = 64 / EB;
+  static constexpr int NW = WGM * WGN, NT = 64 * NW;
+  static constexpr int HH = TH + 1, RS = 17, HPIX = HH * RS, APS = 96;
+  static constexpr int A_BYTES = HPIX * APS;
+  static constexpr int B_BYTES = 3 * BN * 64;
+  static constexpr int NPV = (HPIX * 4 + NT - 1) / NT;
+  static constexpr int NPIECE = 3 * BN / 16;
+  static constexpr int BM = TH * 16;
+  static constexpr int TP = TH / WGM, TC = BN / WGN / 16;
+  static constexpr int ESB = BN * EB + 16;
+  static constexpr int MAIN = 2 * A_BYTES + 2 * B_BYTES;
+  static constexpr int ESLOTS = (BN / VE > 16) ? NW * 4 / (BN / VE / 16) : NW * 4;
+  static constexpr int EPI = BM * ESB + ESLOTS * BN * 2 * 4;
+  static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
+  static_assert(TH % WGM == 0 && BN % (16 * WGN) == 0 && NW == 8, "wave layout");
+  static_assert(4 * TP * TC <= 32, "accumulator budget (four parity classes)");
+  static_assert(SMEM <= 160 * 1024, "LDS image exceeds the 160 KiB of a CU");
+};
+
+template <typename T, int TH, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_s2dg_kernel(const HaloParams p) {
+  using Cfg = S2dCfg<T, TH, BN, WGM, WGN>;
+  constexpr int EB = Cfg::EB, VE = Cfg::VE, CK = Cfg::CK, HPIX = Cfg::HPIX, NPV = Cfg::NPV, NT = Cfg::NT, NW = Cfg::NW;
+  constexpr int TP = Cfg::TP, TC = Cfg::TC, APS = Cfg::APS, NPIECE = Cfg::NPIECE, RS = Cfg::RS;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Abuf = smem;
+  char* const Bbuf = smem + 2 * Cfg::A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int bt = blockIdx.x;
+  const int ky = blockIdx.y;
+  if ((gridDim.x & 7) == 0) bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);        // contiguous runs of tiles per XCD
+  const int tx = bt % p.tiles_x;
+  bt /= p.tiles_x;
+  const int ty = bt % p.tiles_y;
+  const int n = bt / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 16;                    // tile origin in dz
+  const int n0 = ky * BN;
+
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.s0.ptr, p.s0.bytes);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
+
+  const int hv = tid & 3;
+  int h_full[NPV];
+#pragma unroll
+  for (int i = 0; i < NPV; ++i) {
+    const int hp = (tid >> 2) + i * (NT / 4);
+    const int hy = hp / RS, hx = hp - hy * RS;
+    const int y = y0 + hy, x = x0 + hx;
+    const bool ok = hp < HPIX && y < p.Hi && x < p.Wi;
+    h_full[i] = ok ? (n * p.Hi + y) * p.Wi + x : -1;
+  }
+  u32x4_t areg[NPV];
+  auto load_halo = [&](int cc) {
+    const int cl = cc * CK + hv * VE;
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const uint32_t off = (uint32_t)(h_full[i] * p.s0.C + cl) * (uint32_t)EB;
+      areg[i] = buf_load16(rs0, h_full[i] >= 0 ? off : kOOB);
+    }
+  };
+  auto store_halo = [&](char* A) {
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int hp = (tid >> 2) + i * (NT / 4);
+      if (hp < HPIX) *reinterpret_cast<u32x4_t*>(A + hp * APS + hv * 16) = areg[i];
+    }
+  };
+  const uint32_t slab_bytes = (uint32_t)p.K * 64u;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto dma_b = [&](int cc, int s, int buf) {
+#pragma unroll
+    for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
+      const int pc = wave + i * NW;
+      if (NPIECE % NW == 0 || pc < NPIECE) {
+        const int r = pc / (BN / 16), sub = pc - r * (BN / 16);
+        const uint32_t goff = (uint32_t)(cc * 9 + 3 * r + s) * slab_bytes + (uint32_t)(n0 + sub * 16) * 64u;
+        char* dst = Bbuf + buf * Cfg::B_BYTES + (r * BN + sub * 16) * 64;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, lane16, goff, 0, 0);
+      }
+    }
+  };
+
+  const int wrow0 = (wave / WGN) * TP;
+  const int wch0 = (wave % WGN) * (TC * 16);
+  f32x4_t acc[4][TC][TP];                                  // [class (y & 1) * 2 + (x & 1)]
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) acc[q][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int li = lane & 15, kg = lane >> 4;
+  const int a_lane = (wrow0 * RS + li) * APS + kg * 16;
+  const int b_lane = (wch0 + li) * 64 + ((kg ^ swz(li)) << 4);
+
+  auto compute = [&](const char* A, const char* B, auto s_c) {
+    constexpr int s = decltype(s_c)::value;
+    u32x4_t X[TP + 1], W[3][TC];
+#pragma unroll
+    for (int h = 0; h < TP + 1; ++h) X[h] = *reinterpret_cast<const u32x4_t*>(A + ((s == 0 ? 1 : 0) + h * RS) * APS);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int a = 0; a < TC; ++a) W[r][a] = *reinterpret_cast<const u32x4_t*>(B + (r * BN + a * 16) * 64);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      constexpr int px = s != 1 ? 1 : 0;
+      const int q = (r != 1 ? 2 : 0) + px, di = r == 0 ? 1 : 0;
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[q][a][b] = Mma<T>::run(W[r][a], X[b + di], acc[q][a][b]);
+    }
+  };
+
+  load_halo(0);
+  dma_b(0, 0, 0);
+  store_halo(Abuf);
+  __syncthreads();
+  int st = 0;
+  for (int cc = 0; cc < p.nchunks; ++cc) {
+    const bool next_chunk = cc + 1 < p.nchunks;
+    const char* A = Abuf + (cc & 1) * Cfg::A_BYTES + a_lane;
+    char* const Anext = Abuf + ((cc + 1) & 1) * Cfg::A_BYTES;
+    // stage 0
+    dma_b(cc, 1, (st + 1) & 1);
+    if (next_chunk) load_halo(cc + 1);
+    compute(A, Bbuf + (st & 1) * Cfg::B_BYTES + b_lane, std::integral_constant<int, 0>{});
+    __syncthreads();
+    ++st;
+    // stage 1
+    dma_b(cc, 2, (st + 1) & 1);
+    compute(A, Bbuf + (st & 1) * Cfg::B_BYTES + b_lane, std::integral_constant<int, 1>{});
+    if (next_chunk) store_halo(Anext);
+    __syncthreads();
+    ++st;
+    // stage 2
+    if (next_chunk) dma_b(cc + 1, 0, (st + 1) & 1);
+    compute(A, Bbuf + (st & 1) * Cfg::B_BYTES + b_lane, std::integral_constant<int, 2>{});
+    __syncthreads();
+    ++st;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q) __syncthreads();                                // the previous class's tile has left LDS
+    halo_epilogue<T, TH, BN, TP, TC, NT, false, 2>(smem, acc[q], p, n, y0, x0, n0, wrow0, wch0, q >> 1, q & 1);
+  }
+}
+
+// ---- software-pipelined form of the column-staged kernel for the K >= 128 classes (layers 2-4, decoder blocks 0-1: the dominant
+// kernel of the training step).  With 111 KiB of LDS only ONE workgroup of conv3x3_col_kernel fits a CU, its eight waves run in
+// step, and after every stage barrier all of them need their first operand fragments at the same moment: the 14 fragment reads of
+// every wave queue up behind each other on the 128 B/clk LDS port while no MFMA is in flight (in-kernel stamps, r02: 2,600 cycles
+// per stage against 1,536 cycles of MFMA work per SIMD).  Here the stage barrier sits INSIDE the MFMA sequence:
+//     top of stage st : fragments of filter rows 0 and 1 + the halo rows are already in registers (read during stage st - 1)
+//                       read filter row 2  |  MFMAs of filter rows 0, 1
+//     s_waitcnt vmcnt(DMAW) lgkmcnt(0); s_barrier      -> weights of stage st + 1 have landed, nobody reads buffer st any more
+//                       LDS-DMA of stage st + 3 into the buffer of stage st  |  fragment reads of stage st + 1  |  MFMAs of filter row 2
+// so the reads of the next stage travel under 16 MFMAs per wave and the MFMA pipe only sees the barrier's own latency.  That
+// needs three weight buffers (a stage's weights are requested three stages ahead), a partial vmcnt wait (only the DMAs issued
+// during the previous stage may still be in flight — they are the youngest vector-memory operations of every wave by
+// construction, the halo loads are issued in front of them) and two fragment sets in registers: 256 registers per wave instead
+// of 128 (one workgroup per CU either way).  Same operand order, same accumulation order per accumulator (filter row 0, 1, 2 of
+// every stage), same epilogue: bit-identical to conv3x3_col_kernel.
+template <typename T, int TH, int BN, int WGM, int WGN>
+struct ColqCfg : ColCfg<T, TH, BN, WGM, WGN, true> {
+  using Base = ColCfg<T, TH, BN, WGM, WGN, true>;
+  static constexpr int MAIN = 2 * Base::A_BYTES + 3 * Base::B_BYTES;
+  static constexpr int SMEM = MAIN > Base::EPI ? MAIN : Base::EPI;
+  static constexpr int DMAW = Base::NPIECE / Base::NW;           // LDS-DMA instructions per wave and stage
+  static_assert(Base::NPIECE % Base::NW == 0, "every wave must issue the same number of weight DMAs per stage (partial vmcnt wait)");
+  static_assert(DMAW >= 1 && DMAW <= 15, "vmcnt immediate");
+  static_assert(SMEM <= 160 * 1024, "LDS image exceeds the 160 KiB of a CU");
+};
+
+template <typename T, int TH, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_colq_kernel(const HaloParams p) {
+  using Cfg = ColqCfg<T, TH, BN, WGM, WGN>;
+  constexpr int EB = Cfg::EB, VE = Cfg::VE, CK = Cfg::CK, HPIX = Cfg::HPIX, NPV = Cfg::NPV, NT = Cfg::NT, NW = Cfg::NW;
+  constexpr int TP = Cfg::TP, TC = Cfg::TC, APS = Cfg::APS, NPIECE = Cfg::NPIECE;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Abuf = smem;
+  char* const Bbuf = smem + 2 * Cfg::A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int bt = blockIdx.x;
+  int ky = blockIdx.y;
+  if (p.kyn > 0) {                                           // see conv3x3_col_kernel
+    const int j = bt >> 3;
+    ky = j % p.kyn;
+    bt = (bt & 7) * (int)((gridDim.x / p.kyn) >> 3) + j / p.kyn;
+  } else if (p.kyn < 0) {
+    const int kn = -p.kyn, xcd = bt & 7;
+    ky = xcd % kn;
+    bt = (xcd / kn) * (int)(gridDim.x >> 3) + (bt >> 3);
+  } else if ((gridDim.x & 7) == 0) {
+    bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);
+  }
+  const int tx = bt % p.tiles_x;
+  bt /= p.tiles_x;
+  const int ty = bt % p.tiles_y;
+  const int n = bt / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const int n0 = ky * BN;
+
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.s0.ptr, p.s0.bytes);
+  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.s1.ptr ? p.s1.ptr : p.s0.ptr, p.s1.ptr ? p.s1.bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
+
   const int hv = tid & 3;
   int h_full[NPV], h_half[NPV];
   const int Hh = p.H >> 1, Wh = p.W >> 1;
@@ -633,30 +1065,27 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
       u32x4_t v = areg[i];
       if (aff) {
         v = AffineRelu<T>::run(v, sc, sh, relu);
-        if (h_full[i] < 0) v = u32x4_t{0, 0, 0, 0};     // zero padding is applied after BN+ReLU
+        if (h_full[i] < 0) v = u32x4_t{0, 0, 0, 0};
       }
       *reinterpret_cast<u32x4_t*>(A + hp * APS + hv * 16) = v;
     }
   };
 
-  // weights of stage (chunk cc, filter column s) -> weight buffer `buf`: slot r = tap (r, s); data-gradient mode takes tap 8 - t
-  const uint32_t slab_bytes = (uint32_t)p.K * 64u;         // one (chunk, tap) slab of the halo pack
+  // weights of stage (chunk cc, filter column s) -> weight buffer s
+  const uint32_t slab_bytes = (uint32_t)p.K * 64u;
   const uint32_t lane16 = (uint32_t)lane * 16u;
-  auto dma_b = [&](int cc, int s, int buf) {
+  auto dma_b = [&](int cc, int s) {
 #pragma unroll
-    for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
-      const int pc = wave + i * NW;                        // wave-uniform
-      if (NPIECE % NW == 0 || pc < NPIECE) {
-        const int r = pc / (BN / 16), sub = pc - r * (BN / 16);
-        const int tap = p.flip ? 8 - (3 * r + s) : 3 * r + s;
-        const uint32_t goff = (uint32_t)(cc * 9 + tap) * slab_bytes + (uint32_t)(n0 + sub * 16) * 64u;
-        char* dst = Bbuf + buf * Cfg::B_BYTES + (r * BN + sub * 16) * 64;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, lane16, goff, 0, 0);
-      }
+    for (int i = 0; i < Cfg::DMAW; ++i) {
+      const int pc = wave + i * NW;
+      const int r = pc / (BN / 16), sub = pc - r * (BN / 16);
+      const int tap = p.flip ? 8 - (3 * r + s) : 3 * r + s;
+      const uint32_t goff = (uint32_t)(cc * 9 + tap) * slab_bytes + (uint32_t)(n0 + sub * 16) * 64u;
+      char* dst = Bbuf + s * Cfg::B_BYTES + (r * BN + sub * 16) * 64;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, lane16, goff, 0, 0);
     }
   };
 
-  // ---- accumulators and per-lane fragment bases
   const int wrow0 = (wave / WGN) * TP;
   const int wch0 = (wave % WGN) * (TC * 16);
   f32x4_t acc[TC][TP];
@@ -668,85 +1097,98 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
   const int a_lane = (wrow0 * 18 + li) * APS + kg * 16;
   const int b_lane = (wch0 + li) * 64 + ((kg ^ swz(li)) << 4);
 
-  auto compute = [&](const char* A, const char* B) {
-    u32x4_t X[TP + 2], W[3][TC];
+  // fragment sets: X = halo rows (rows 0..TP-1 arrive during the previous stage, rows TP and TP+1 during this one), Wr = filter rows
+  u32x4_t X[TP + 2], W0[TC], W1[TC], W2[TC];
+  auto rd = [](const char* q) { return *reinterpret_cast<const u32x4_t*>(q); };
+  auto mfma_row = [&](const u32x4_t (&Wr)[TC], int r) {
 #pragma unroll
-    for (int h = 0; h < TP + 2; ++h) X[h] = *reinterpret_cast<const u32x4_t*>(A + h * (18 * APS));
+    for (int a = 0; a < TC; ++a)
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int a = 0; a < TC; ++a) W[r][a] = *reinterpret_cast<const u32x4_t*>(B + (r * BN + a * 16) * 64);
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int a = 0; a < TC; ++a)
-#pragma unroll
-        for (int b = 0; b < TP; ++b) acc[a][b] = Mma<T>::run(W[r][a], X[b + r], acc[a][b]);
-    // issue order: [halo rows + filter row 0][filter row 1][MFMAs row 0][filter row 2][MFMAs row 1][MFMAs row 2]
-    constexpr int NM = TC * TP * (sizeof(T) == 4 ? 4 : 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, TP + 2 + TC, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, TC, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, TC, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      for (int b = 0; b < TP; ++b) acc[a][b] = Mma<T>::run(Wr[a], X[b + r], acc[a][b]);
   };
+  constexpr int NM = TC * TP * (sizeof(T) == 4 ? 4 : 1);       // MFMA instructions per filter row
+  constexpr int kWaitPart = (Cfg::DMAW & 0xF) | 0x70;          // s_waitcnt vmcnt(DMAW) lgkmcnt(0)  (expcnt untouched)
+  constexpr int kWaitAll = 0x0070;                              // s_waitcnt vmcnt(0) lgkmcnt(0)
+  static_assert(TP % 2 == 0, "the next stage's halo rows are fetched in two halves");
 
-#ifdef VK_STAMP
-  unsigned long long t_begin, t_pro, tk_load = 0, tk_comp = 0, tk_store = 0, tk_bar = 0;
-  VK_T(t_begin)
-#endif
-  // ---- prologue: first chunk's halo + stage 0 weights (split-K: this workgroup's slice of the chunks)
+  // ---- prologue: first chunk's halo + the weights of its three stages
   const int ksp = p.ksplit > 1 ? p.ksplit : 1;
   const int c_begin = (int)((long)p.nchunks * blockIdx.z / ksp), c_end = (int)((long)p.nchunks * (blockIdx.z + 1) / ksp);
   load_halo(c_begin);
-  dma_b(c_begin, 0, 0);
+  dma_b(c_begin, 0);
+  dma_b(c_begin, 1);
+  dma_b(c_begin, 2);
   store_halo(Abuf);
   __syncthreads();                                        // also drains the LDS-DMA (vmcnt(0))
-  VK_T(t_pro)
+#pragma unroll
+  for (int h = 0; h < TP; ++h) X[h] = rd(Abuf + a_lane + h * (18 * APS));
+#pragma unroll
+  for (int a = 0; a < TC; ++a) W0[a] = rd(Bbuf + b_lane + (a * 16) * 64);
 
-  int st = 0;
   for (int cc = c_begin; cc < c_end; ++cc) {
     const bool next_chunk = cc + 1 < c_end;
-    const char* A = Abuf + (ADB ? ((cc - c_begin) & 1) * Cfg::A_BYTES : 0) + a_lane;
-    char* const Anext = Abuf + (ADB ? ((cc - c_begin + 1) & 1) * Cfg::A_BYTES : 0);
+    const char* const Acur = Abuf + ((cc - c_begin) & 1) * Cfg::A_BYTES + a_lane;
+    char* const Anext = Abuf + ((cc - c_begin + 1) & 1) * Cfg::A_BYTES;
 #pragma unroll
-    for (int s = 0; s < 3; ++s, ++st) {
-#ifdef VK_STAMP
-      unsigned long long t0, t1, t2, t3, t4;
-#endif
-      VK_T(t0)
-      // next stage's weights into the other buffer (all waves passed the barrier that closed its last readers)
-      if (!(p.dbg & 2)) {
-        if (s < 2) dma_b(cc, s + 1, (st + 1) & 1);
-        else if (next_chunk) dma_b(cc + 1, 0, (st + 1) & 1);
+    for (int s = 0; s < 3; ++s) {
+      const char* const As = Acur + s * APS;
+      const char* const Bs = Bbuf + s * Cfg::B_BYTES + b_lane;
+      // the next stage's halo rows: same image one column on, or the next chunk's image (published by the barrier of stage 1)
+      const bool more = s < 2 || next_chunk;
+      const char* const An = s < 2 ? Acur + (s + 1) * APS : Anext + a_lane;
+      const char* const Bn = Bbuf + ((s + 1) % 3) * Cfg::B_BYTES + b_lane;
+      u32x4_t Xn[TP], W0n[TC];
+      // -- filter row 0 (operands in registers); under it: halo row TP + filter row 1, first half of the next stage's rows
+      X[TP] = rd(As + TP * (18 * APS));
+#pragma unroll
+      for (int a = 0; a < TC; ++a) W1[a] = rd(Bs + (BN + a * 16) * 64);
+      if (more) {
+#pragma unroll
+        for (int h = 0; h < TP / 2; ++h) Xn[h] = rd(An + h * (18 * APS));
       }
-      if (s == 0 && next_chunk && !(p.dbg & 4)) load_halo(cc + 1);
-      VK_T(t1)
-      compute(A + s * APS, Bbuf + (st & 1) * Cfg::B_BYTES + b_lane);
-      VK_T(t2)
-      if (ADB) {
-        if (s == 1 && next_chunk && !(p.dbg & 4)) store_halo(Anext);
-      } else {
-        if (s == 2 && next_chunk && !(p.dbg & 4)) {
-          __syncthreads();                                // every wave is done reading this chunk's halo
-          store_halo(Anext);
-        }
+      mfma_row(W0, 0);
+      // -- filter row 1; under it: halo row TP + 1 + filter row 2, second half of the next stage's rows
+      X[TP + 1] = rd(As + (TP + 1) * (18 * APS));
+#pragma unroll
+      for (int a = 0; a < TC; ++a) W2[a] = rd(Bs + (2 * BN + a * 16) * 64);
+      if (more) {
+#pragma unroll
+        for (int h = TP / 2; h < TP; ++h) Xn[h] = rd(An + h * (18 * APS));
       }
-      VK_T(t3)
-      if (!(p.dbg & 8)) __syncthreads();
-      VK_T(t4)
-#ifdef VK_STAMP
-      tk_load += t1 - t0; tk_comp += t2 - t1; tk_store += t3 - t2; tk_bar += t4 - t3;
-#endif
+      mfma_row(W1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1 + TC + TP / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1 + TC + TP / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      if (s == 1 && next_chunk) store_halo(Anext);
+      // every wave: its reads of this stage's weights / halo rows have returned, its halo stores are in LDS, and of its vector
+      // memory operations only the DMAW youngest (the weights of stage st + 2) may still be in flight
+      asm volatile("" ::: "memory");
+      if (next_chunk) __builtin_amdgcn_s_waitcnt(kWaitPart);
+      else __builtin_amdgcn_s_waitcnt(kWaitAll);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (next_chunk) {
+        if (s == 0) load_halo(cc + 1);                      // in front of the DMAs: those stay the youngest operations
+        dma_b(cc + 1, s);                                   // stage st + 3 -> the buffer every wave has just finished reading
+      }
+      // -- filter row 2; under it: the next stage's filter row 0 (its weights became visible with the barrier)
+      if (more) {
+#pragma unroll
+        for (int a = 0; a < TC; ++a) W0n[a] = rd(Bn + (a * 16) * 64);
+      }
+      mfma_row(W2, 2);
+      if (more) {
+#pragma unroll
+        for (int h = 0; h < TP; ++h) X[h] = Xn[h];
+#pragma unroll
+        for (int a = 0; a < TC; ++a) W0[a] = W0n[a];
+      }
     }
   }
-#ifdef VK_STAMP
-  unsigned long long te0, te1;
-  VK_T(te0)
-#endif
+  __syncthreads();                                          // every wave is done with the operand buffers: the epilogue reuses them
+
   if (p.ksplit > 1) {
-    // partial tile straight from the accumulators: lane = pixel li, four consecutive channels per 16-byte store
     float* sl = p.slab + (size_t)blockIdx.z * ((size_t)p.N * p.H * p.W * p.K);
 #pragma unroll
     for (int a = 0; a < TC; ++a)
@@ -758,13 +1200,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
     return;
   }
   halo_epilogue<T, TH, BN, TP, TC, NT, (BN <= 64 && TH == 16)>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
-#ifdef VK_STAMP
-  VK_T(te1)
-  if (p.stamps && lane == 0) {
-    unsigned long long* o = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
-    o[0] = tk_load; o[1] = tk_comp; o[2] = tk_store; o[3] = tk_bar; o[4] = te1 - te0; o[5] = t_pro - t_begin; o[6] = te1 - t_begin; o[7] = st;
-  }
-#endif
 }
 
 // ---- persistent form of the column-staged kernel for the K < 128 classes (layer1, decoder blocks 2-4: thousands of tiles, each a
@@ -1175,9 +1610,22 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(size_t n4, int splits, co
   }
 }
 
+template <bool PIPE, typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW, int STR>
+struct ColLaunch {
+  using Cfg = ColCfg<T, TH, BN, WGM, WGN, ADB, STR>;
+  static const void* kernel() { return (const void*)conv3x3_col_kernel<T, TH, BN, WGM, WGN, ADB, MINW, STR>; }
+};
 template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW>
+struct ColLaunch<true, T, TH, BN, WGM, WGN, ADB, MINW, 1> {
+  using Cfg = ColqCfg<T, TH, BN, WGM, WGN>;
+  static const void* kernel() { return (const void*)conv3x3_colq_kernel<T, TH, BN, WGM, WGN>; }
+};
+
+template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW, bool PIPE = false, int STR = 1>
 static int launch_col(HaloParams p, hipStream_t st) {
-  using Cfg = ColCfg<T, TH, BN, WGM, WGN, ADB>;
+  using Sel = ColLaunch<PIPE, T, TH, BN, WGM, WGN, ADB, MINW, STR>;
+  using Cfg = typename Sel::Cfg;
+  const void* const kernel = Sel::kernel();
   p.tiles_x = (p.W + 15) / 16;
   p.tiles_y = (p.H + TH - 1) / TH;
   dim3 grid((unsigned)(p.N * p.tiles_y * p.tiles_x), (unsigned)((p.K + BN - 1) / BN), 1);
@@ -1202,23 +1650,28 @@ static int launch_col(HaloParams p, hipStream_t st) {
     p.kyn = (int)grid.y;
     grid.x *= grid.y;
     grid.y = 1;
+    const char* km = getenv("VK_COL_KYMODE");               // w: weights-stationary XCDs (needs 8 % kyn == 0 and whole runs of tiles)
+    // default: on the layers whose weights do not fit an XCD's L2 beside the activations (>= 3 MB: layer 4, decoder block 0 conv1;
+    // measured r02: +2-4 % there, -2 % on the 1.2 MB layer-3 weights)
+    const bool wst = km ? km[0] == 'w' : (size_t)p.w_bytes >= (3u << 20);
+    if (PIPE && wst && 8 % p.kyn == 0 && (grid.x / 8) * (8 / p.kyn) * p.kyn == grid.x) p.kyn = -p.kyn;
   }
   static bool attr_done = false;
   if (!attr_done && Cfg::SMEM > 64 * 1024) {
-    VK_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_col_kernel<T, TH, BN, WGM, WGN, ADB, MINW>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+    VK_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
     attr_done = true;
   }
   {
     static const std::string tag_f = std::string("col_") + (sizeof(T) == 4 ? "f32" : "16b") + "_t" + std::to_string(TH) + "_bn" + std::to_string(BN) +
-                                     "_w" + std::to_string(WGM * WGN);
+                                     "_w" + std::to_string(WGM * WGN) + (STR == 2 ? "_s2" : "");
     static const std::string tag_d = tag_f + "_dgrad";
     const double macs = (double)p.N * p.H * p.W * p.K * 9.0 * p.C;
-    const double bytes = ((double)p.N * p.H * p.W * (p.C + p.K) + 9.0 * p.K * p.C) * sizeof(T);
+    const double bytes = ((double)p.N * ((double)p.Hi * p.Wi * p.C + (double)p.H * p.W * p.K) + 9.0 * p.K * p.C) * sizeof(T);
     const std::string& btag = p.flip ? tag_d : tag_f;
     const std::string dtag = getenv("VK_PROF_DETAIL") ? btag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) : btag;
     vkh::ProfScope ps(dtag.c_str(), st, 2.0 * macs, bytes);
-    hipLaunchKernelGGL((conv3x3_col_kernel<T, TH, BN, WGM, WGN, ADB, MINW>), grid, dim3(Cfg::NT), Cfg::SMEM, st, p);
+    void* args[] = {(void*)&p};
+    VK_CHECK_HIP(hipLaunchKernel(kernel, grid, dim3(Cfg::NT), args, Cfg::SMEM, st));
   }
   if (ks > 1) {
     vkh::ProfScope ps("splitk_reduce", st, 0.0, (double)out_elems * (4.0 * ks + sizeof(T)));
@@ -1298,8 +1751,13 @@ static int col_select(const HaloParams& p, hipStream_t st) {
     if (alt == 3 || (alt != 2 && alt != 7 && p.nchunks <= 2)) return launch_col<T, 8, 128, 2, 2, false, 2>(p, st);
     // too few 16x16 tiles to fill the chip (layer4: 256 workgroups of 8x16x128): the same tile on EIGHT waves (4 rows x 32
     // channels each) — one workgroup per CU either way, but two waves per SIMD instead of one (L4 dgrad 46.6 -> 41.3 us)
-    if (alt == 7 || (alt != 2 && tiles16 * kt < 256)) return launch_col<T, 8, 128, 2, 4, true, 2>(p, st);
-    return launch_col<T, 16, 128, 4, 2, true, 2>(p, st);                    // 8 waves, 4 rows x 64 channels per wave
+    // the 8-wave tiles run software-pipelined (conv3x3_colq_kernel); VK_COL_PIPE=0 (diagnostic / tests): the plain stage loop
+    const char* const pipe_s = getenv("VK_COL_PIPE");
+    const bool pipe = !(pipe_s && atoi(pipe_s) == 0);
+    if (alt == 7 || (alt != 2 && tiles16 * kt < 256))
+      return pipe ? launch_col<T, 8, 128, 2, 4, true, 1, true>(p, st) : launch_col<T, 8, 128, 2, 4, true, 2>(p, st);
+    return pipe ? launch_col<T, 16, 128, 4, 2, true, 1, true>(p, st)       // 8 waves, 4 rows x 64 channels per wave
+                : launch_col<T, 16, 128, 4, 2, true, 2>(p, st);
   }
   if (p.K >= 64) return launch_small<T, 64>(p, st);
   // measured and rejected (r02): 32 x 16 pixel tiles for K <= 32 on the 256x256 / 512x512 maps (half the prologues / epilogues per
@@ -1344,21 +1802,51 @@ static int launch_c16(HaloParams p, hipStream_t st) {
   return VK_OK;
 }
 
+template <typename T, int BN>
+static int launch_s2dg(HaloParams p, hipStream_t st) {
+  using Cfg = S2dCfg<T, 8, BN, 4, 2>;
+  p.tiles_x = (p.Wi + 15) / 16;
+  p.tiles_y = (p.Hi + 7) / 8;
+  dim3 grid((unsigned)(p.N * p.tiles_y * p.tiles_x), (unsigned)((p.K + BN - 1) / BN), 1);
+  static bool attr_done = false;
+  if (!attr_done && Cfg::SMEM > 64 * 1024) {
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_s2dg_kernel<T, 8, BN, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+    attr_done = true;
+  }
+  {
+    static const std::string tag = std::string("s2dg_") + (sizeof(T) == 4 ? "f32" : "16b") + "_bn" + std::to_string(BN);
+    const std::string dtag = getenv("VK_PROF_DETAIL") ? tag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) : tag;
+    const double bytes = ((double)p.N * ((double)p.Hi * p.Wi * p.C + (double)p.H * p.W * p.K * (p.accumulate ? 2.0 : 1.0)) + 9.0 * p.K * p.C) * sizeof(T);
+    vkh::ProfScope ps(dtag.c_str(), st, 2.0 * (double)p.N * p.Hi * p.Wi * p.K * 9.0 * p.C, bytes);
+    hipLaunchKernelGGL((conv3x3_s2dg_kernel<T, 8, BN, 4, 2>), grid, dim3(Cfg::NT), Cfg::SMEM, st, p);
+  }
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
 // returns VK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the tap-by-tap kernel)
 // w: halo pack (vk_halo_pack) when `packed`, plain [K][3][3][C] otherwise — only the C == 16 kernel takes the plain layout
 int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, void* y1, int split_k1, int accumulate, double* stats,
                      int pool2, const vk_bnr* bnr, hipStream_t st, void* workspace, size_t workspace_bytes) {
-  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->H != d->Ho || d->W != d->Wo) return VK_ERR_UNSUPPORTED;
+  // stride 2 (forward only): the K >= 128 openers of layers 2-4 — even input, no upsample / concat / fused gradient epilogues
+  const bool s2 = d->stride == 2 && !d->transposed && d->H == 2 * d->Ho && d->W == 2 * d->Wo && d->K >= 128 && !d->src0.up && !d->src1.ptr &&
+                  !pool2 && !bnr && !accumulate && !split_k1 && !getenv("VK_NO_S2_TILE");
+  // stride-2 data gradient: dz [H][W] -> dx [2H][2W]; plain or accumulating store only
+  const bool s2d = d->stride == 2 && d->transposed && d->Ho == 2 * d->H && d->Wo == 2 * d->W && d->K >= 64 && d->K % 64 == 0 && !d->src0.up &&
+                   !d->src1.ptr && !d->src0.scale && !pool2 && !bnr && !split_k1 && !getenv("VK_NO_S2_TILE");
+  if (d->R != 3 || d->S != 3 || d->pad != 1) return VK_ERR_UNSUPPORTED;
+  if (!s2 && !s2d && (d->stride != 1 || d->H != d->Ho || d->W != d->Wo)) return VK_ERR_UNSUPPORTED;
   const int eb = d->dtype == VK_F32 ? 4 : 2;
   const int ck = 64 / eb;
   const int C = d->src0.C + (d->src1.ptr ? d->src1.C : 0);
-  const bool c16 = (eb == 2) && C == 16 && !d->src1.ptr && !d->src0.up;
+  const bool c16 = (eb == 2) && C == 16 && !d->src1.ptr && !d->src0.up && !s2 && !s2d;
   if (c16 ? packed : !packed) return VK_ERR_UNSUPPORTED;
   if (!c16 && (d->src0.C % ck || (d->src1.ptr && d->src1.C % ck))) return VK_ERR_UNSUPPORTED;
   if (d->K % 16) return VK_ERR_UNSUPPORTED;
   if (pool2 && ((d->H | d->W) & 1)) return VK_ERR_UNSUPPORTED;
   if (d->src1.ptr && d->src1.up) return VK_ERR_UNSUPPORTED;
   if ((size_t)d->N * d->H * d->W * C * eb >= (1ull << 31) || (size_t)d->N * d->H * d->W >= (1ull << 31)) return VK_ERR_UNSUPPORTED;
+  if (s2d && (size_t)d->N * d->Ho * d->Wo * d->K * eb >= (1ull << 32)) return VK_ERR_UNSUPPORTED;
   HaloParams p;
   auto mk = [&](const vk_src& s) {
     HaloSrc h;
@@ -1375,7 +1863,8 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, 
   p.ld0 = split_k1 ? split_k1 : d->K;
   p.ld1 = split_k1 ? d->K - split_k1 : 0;
   p.stats = stats;
-  p.N = d->N; p.H = d->H; p.W = d->W; p.K = d->K; p.C = C;
+  p.N = d->N; p.H = d->Ho; p.W = d->Wo; p.K = d->K; p.C = C;
+  p.Hi = d->H; p.Wi = d->W;
   p.flip = d->transposed;
   p.accumulate = accumulate;
   p.pool2 = pool2;
@@ -1399,6 +1888,28 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, 
     return d->K >= 32 ? launch_c16<f16_t, 32>(p, st) : launch_c16<f16_t, 16>(p, st);
   }
   p.tiles_x = p.tiles_y = 0;
+  if (s2d) {
+    p.flip = 0;
+    // 128 output channels per workgroup unless that leaves CUs idle (layer 4: 64 dz tiles x 2 channel tiles)
+    const long tiles = (long)d->N * ((d->H + 7) / 8) * ((d->W + 15) / 16);
+    const bool wide = d->K % 128 == 0 && tiles * (d->K / 128) >= 256;
+    switch (d->dtype) {
+      case VK_F32: return wide ? launch_s2dg<float, 128>(p, st) : launch_s2dg<float, 64>(p, st);
+      case VK_BF16: return wide ? launch_s2dg<bf16_t, 128>(p, st) : launch_s2dg<bf16_t, 64>(p, st);
+      case VK_F16: return wide ? launch_s2dg<f16_t, 128>(p, st) : launch_s2dg<f16_t, 64>(p, st);
+    }
+    return VK_ERR_ARG;
+  }
+  if (s2) {
+    p.slab = nullptr;                                      // no split-K on this path
+    p.slab_bytes = 0;
+    switch (d->dtype) {
+      case VK_F32: return launch_col<float, 8, 128, 2, 4, false, 1, false, 2>(p, st);
+      case VK_BF16: return launch_col<bf16_t, 8, 128, 2, 4, false, 1, false, 2>(p, st);
+      case VK_F16: return launch_col<f16_t, 8, 128, 2, 4, false, 1, false, 2>(p, st);
+    }
+    return VK_ERR_ARG;
+  }
   switch (d->dtype) {
     case VK_F32: return halo_select<float>(p, st);
     case VK_BF16: return halo_select<bf16_t>(p, st);

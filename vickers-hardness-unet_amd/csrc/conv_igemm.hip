@@ -544,8 +544,8 @@ int conv_fwd_impl(const vk_conv_desc* d, const void* w, int packed, void* y, voi
   }
   VK_CHECK_ARG(!d->src0.up || (d->H % 2 == 0 && d->W % 2 == 0), "vk_conv_fwd: upsampled source needs even H, W");
   VK_CHECK_ARG(!(d->src1.ptr && d->src1.up), "vk_conv_fwd: only src0 may be upsampled");
-  if (halo_enabled() && (!d->transposed || d->stride == 1)) {
-    // 3x3 stride-1 convolutions (and their data gradients) go to the LDS-staged halo kernel
+  if (halo_enabled()) {
+    // 3x3 stride-1 convolutions (and their data gradients) and the stride-2 forward go to the LDS-staged tile kernels
     const int rc = conv3x3_halo_try(d, w, packed, y, y1, split_k1, accumulate, stats, pool2, bnr, st, workspace, workspace_bytes);
     if (rc != VK_ERR_UNSUPPORTED) return rc;
   }
@@ -661,7 +661,13 @@ extern "C" int vk_halo_pack(vk_dtype dtype, int rows, int red, const void* src, 
 }
 
 extern "C" int vk_conv_uses_halo_pack(const vk_conv_desc* d) {
-  if (!d || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->H != d->Ho || d->W != d->Wo) return 0;
+  if (!d || d->R != 3 || d->S != 3 || d->pad != 1) return 0;
+  const bool s2 = d->stride == 2 && !d->transposed && d->H == 2 * d->Ho && d->W == 2 * d->Wo && d->K >= 128 && !d->src0.up && !d->src1.ptr &&
+                  !getenv("VK_NO_S2_TILE");                 // the stride-2 forward tile kernel (conv3x3_halo_try)
+  const bool s2d = d->stride == 2 && d->transposed && d->Ho == 2 * d->H && d->Wo == 2 * d->W && d->K >= 64 && d->K % 64 == 0 && !d->src0.up &&
+                   !d->src1.ptr && !d->src0.scale && !getenv("VK_NO_S2_TILE");      // its data gradient (conv3x3_s2dg_kernel)
+  if (s2d && (size_t)d->N * d->Ho * d->Wo * d->K * (d->dtype == VK_F32 ? 4 : 2) >= (1ull << 32)) return 0;
+  if (!s2 && !s2d && (d->stride != 1 || d->H != d->Ho || d->W != d->Wo)) return 0;
   if (vk::is_c16(d)) return 0;
   const int ck = d->dtype == VK_F32 ? 16 : 32;
   if (d->src0.C % ck || (d->src1.ptr && (d->src1.C % ck || d->src1.up)) || d->K % 16) return 0;
