@@ -218,7 +218,7 @@ def main():
             dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
             tag, r = dom
             per_launch_ms = r["ms"] / r["n"]
-            if r["flops"] > 0 and any(k in tag for k in ("igemm", "wgrad", "stem", "halo", "col_")):
+            if r["flops"] > 0 and any(k in tag for k in ("igemm", "wgrad", "stem", "halo", "col_", "colq_", "s2dg_")):
                 peak = PEAK_MFMA_F32 if "f32" in tag else PEAK_MFMA_16B
                 ach = r["flops"] / (r["ms"] * 1e-3)
                 roof = {"kernel": tag, "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
@@ -232,6 +232,11 @@ def main():
             # HBM traffic of the dominant kernel: offline rocprofv3 PMC measurement committed under profiles/ (bench.py itself
             # cannot run the profiler); null when that kernel family was not measured
             roof["algorithmic_bytes_per_launch"] = round(r["bytes"] / r["n"])
+            import re as _re
+            m_ = _re.match(r"(colq?)_(16b|f32)_t(\d+)_bn(\d+)_w(\d+)", tag)
+            if m_:      # the symbol rocprofv3 --stats lists this family under (profiles/r02/*kernel_stats.csv)
+                roof["kernel_symbol"] = (f"vk::conv3x3_{m_.group(1)}_kernel<{'float' if m_.group(2) == 'f32' else ('vk::bf16_t' if args.dtype == 'bf16' else 'vk::f16_t')}, {m_.group(3)}, {m_.group(4)}, ...> "
+                                         f"({m_.group(5)} waves; forward and data-gradient launches)")
             try:
                 tpath = ROOT / "profiles" / "r02" / "traffic.json"
                 tj = json.load(open(tpath))

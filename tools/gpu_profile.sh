@@ -1,16 +1,23 @@
-# bench.py default line + rocprofv3 kernel stats + PMC HBM-traffic passes on a gpurun box:  gpurun --timeout 1200 -- 'bash tools/gpu_profile.sh'
-# then copy gpurun_out/prof3/runc/*_kernel_stats.csv, gpurun_out/traffic3.json and the bench line into profiles/
-mkdir -p gpurun_out
+# bench.py default line + rocprofv3 kernel stats + PMC HBM-traffic passes on a gpurun box:
+#   rm -rf gpurun_out/profrun; gpurun --timeout 1200 -- 'bash tools/gpu_profile.sh'
+# everything to keep lands in gpurun_out/profrun/summary/ (kernel_stats.csv, traffic.json, pmc csv, the bench lines): copy it into profiles/rNN/
 R=$GRAFT_REPO_ROOT
-( time timeout -k 10 500 python bench.py ) > gpurun_out/bench_default.log 2>&1
-echo "rc=$?"; tail -4 gpurun_out/bench_default.log | cut -c1-600
+O=$R/gpurun_out/profrun
+rm -rf $O; mkdir -p $O/summary
+( time timeout -k 10 500 python bench.py ) > $O/summary/bench_default.log 2>&1
+echo "rc=$?"; tail -4 $O/summary/bench_default.log | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof3 $R/gpurun_out/pmc_fetch3 $R/gpurun_out/pmc_write3
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof3 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --prof-steps 0 > $R/gpurun_out/prof3.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --prof-steps 0 > $O/stats.log 2>&1
 echo "stats rc=$?"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --prof-steps 0 > $R/gpurun_out/pmc_fetch3.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --prof-steps 0 > $O/pmc_fetch.log 2>&1
 echo "fetch rc=$?"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --prof-steps 0 > $R/gpurun_out/pmc_write3.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --prof-steps 0 > $O/pmc_write.log 2>&1
 echo "write rc=$?"
-cd $R && python tools/pmc_traffic.py gpurun_out/pmc_fetch3 gpurun_out/pmc_write3 gpurun_out/traffic3.json | head -30
-find gpurun_out/prof3 -name "*kernel_stats.csv" | head; du -sh gpurun_out/prof3 gpurun_out/pmc_fetch3 gpurun_out/pmc_write3
+cd $R && python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/summary/traffic.json | head -12
+find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/summary/kernel_stats.csv \;
+# the bench line WITH the traffic of this very tree: install the fresh traffic file where bench.py looks for it and run the default bench again
+cp $O/summary/traffic.json profiles/r02/traffic.json
+( timeout -k 10 400 python bench.py ) > $O/summary/bench_with_traffic.log 2>&1
+echo "rc=$?"; tail -1 $O/summary/bench_with_traffic.log | cut -c1-300
+timeout -k 10 200 python tools/geom_aug_bench.py > $O/summary/geom_aug_bench.log 2>&1; tail -3 $O/summary/geom_aug_bench.log
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write      # raw traces stay on the box

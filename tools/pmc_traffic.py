@@ -11,10 +11,21 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 
 def family(name):
     """kernel symbol -> the tag bench.py / vk_prof use for that kernel family (forward and data-gradient launches share one)"""
-    m = re.search(r"conv3x3_col_kernel<vk::(\w+), (\d+), (\d+), (\d+), (\d+)", name)
+    m = re.search(r"conv3x3_col_kernel<vk::(\w+), (\d+), (\d+), (\d+), (\d+), \w+, \d+(?:, (\d+))?>", name)
+    if m:
+        t, th, bn, wm, wn, stride = m.groups()
+        return f"col_{'f32' if t == 'float' else '16b'}_t{th}_bn{bn}_w{int(wm) * int(wn)}" + ("_s2" if stride == "2" else "")
+    m = re.search(r"conv3x3_colq_kernel<vk::(\w+), (\d+), (\d+), (\d+), (\d+)>", name)      # the software-pipelined form
+    if m:
+        t, th, bn, wm, wn = m.groups()
+        return f"colq_{'f32' if t == 'float' else '16b'}_t{th}_bn{bn}_w{int(wm) * int(wn)}"
+    m = re.search(r"conv3x3_colp_kernel<vk::(\w+), (\d+), (\d+), (\d+), (\d+)", name)      # the persistent form runs under the plain tag
     if m:
         t, th, bn, wm, wn = m.groups()
         return f"col_{'f32' if t == 'float' else '16b'}_t{th}_bn{bn}_w{int(wm) * int(wn)}"
+    m = re.search(r"conv3x3_s2dg_kernel<vk::(\w+), \d+, (\d+)", name)
+    if m:
+        return f"s2dg_{'f32' if m.group(1) == 'float' else '16b'}_bn{m.group(2)}"
     m = re.search(r"wgrad_halo_kernel<vk::(\w+), (\d+), (\d+), (\w+), (\w+)>", name)
     if m:
         t, kt, ct, ws, ts = m.groups()

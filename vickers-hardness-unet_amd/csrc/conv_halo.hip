@@ -1662,8 +1662,8 @@ static int launch_col(HaloParams p, hipStream_t st) {
     attr_done = true;
   }
   {
-    static const std::string tag_f = std::string("col_") + (sizeof(T) == 4 ? "f32" : "16b") + "_t" + std::to_string(TH) + "_bn" + std::to_string(BN) +
-                                     "_w" + std::to_string(WGM * WGN) + (STR == 2 ? "_s2" : "");
+    static const std::string tag_f = std::string(PIPE ? "colq_" : "col_") + (sizeof(T) == 4 ? "f32" : "16b") + "_t" + std::to_string(TH) + "_bn" +
+                                     std::to_string(BN) + "_w" + std::to_string(WGM * WGN) + (STR == 2 ? "_s2" : "");
     static const std::string tag_d = tag_f + "_dgrad";
     const double macs = (double)p.N * p.H * p.W * p.K * 9.0 * p.C;
     const double bytes = ((double)p.N * ((double)p.Hi * p.Wi * p.C + (double)p.H * p.W * p.K) + 9.0 * p.K * p.C) * sizeof(T);
@@ -1725,8 +1725,9 @@ static int launch_small(const HaloParams& p, hipStream_t st) {
   // (BN = 32) workgroups per CU: dec4.conv1 forward 242 -> 325 us, dec3.conv2 84 -> 108 us; on BN = 64 (equal occupancy) it gains
   // 2-3 % (layer1 forward 61.6 -> 59.6 us) — the co-resident workgroups already hide each other's prologue.  Kept as an opt-in and
   // tested (VK_COL_PERSIST=N: from N tiles on).
+  // r02: on by default for BN = 64 when a workgroup gets at least two tiles (VK_COL_PERSIST=0 switches it off)
   const char* pe = getenv("VK_COL_PERSIST");
-  const long min_tiles = pe ? (atol(pe) == 0 ? -1 : atol(pe)) : -1;
+  const long min_tiles = pe ? (atol(pe) == 0 ? -1 : atol(pe)) : (BN == 64 ? 1024 : -1);
   const bool splitk_wanted = p.slab && !p.stats && !p.bnr_z && !p.accumulate && !p.pool2 && p.split == 0 && total < 128;
   if (min_tiles > 0 && !splitk_wanted && total >= min_tiles) return launch_colp<T, 16, BN, 4, 1, 2>(p, st);
   return launch_col<T, 16, BN, 4, 1, false, 2>(p, st);
