@@ -24,7 +24,11 @@ import sys
 import time
 from pathlib import Path
 
-import torch
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with `hipIpcGetMemHandle: invalid argument` otherwise);
+# the launcher's environment normally carries it already — must be set before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 _T0 = time.perf_counter()
 ROOT = Path(__file__).resolve().parent
