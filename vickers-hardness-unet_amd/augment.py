@@ -146,7 +146,10 @@ class DeviceDataset:
 
     def batch(self, indices: Sequence[int], sampler: Optional[AugmentSampler] = None, draws: Optional[Sequence[dict]] = None
               ) -> Tuple[torch.Tensor, torch.Tensor, List[str]]:
-        """``(x float32 [n,3,S,S], y float32 [n,1,S,S], names)`` for the given items — the tuple ``VickersDataset`` + ``DataLoader``
+        """One stream at a time: the parameter scratch and the CLAHE workspace of the dataset are reused by every call, so
+        batches requested on different streams must be ordered by the caller (consecutive calls on one stream are).
+
+        ``(x float32 [n,3,S,S], y float32 [n,1,S,S], names)`` for the given items — the tuple ``VickersDataset`` + ``DataLoader``
         hand to the training loop (train.py:195-200, 423).  ``sampler=None`` and ``draws=None``: the validation pipeline (no random
         transforms, train.py:114-130).  ``draws``: explicit parameter dicts (tests)."""
         idx = [int(i) for i in indices]
