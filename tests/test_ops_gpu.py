@@ -289,10 +289,18 @@ def test_conv_fwd_upsample_concat(shape, dtn, conv_path):
     assert err <= tol(dt, ref), err
 
 
-@pytest.mark.parametrize("dtn", ["f32", "bf16"])
-def test_stem_fwd(dtn):
+@pytest.mark.parametrize("path", ["tile", "tap"])
+@pytest.mark.parametrize("S", [64, 40, 104])
+@pytest.mark.parametrize("dtn", ["f32", "bf16", "f16"])
+def test_stem_fwd(dtn, S, path, monkeypatch):
+    """7x7 s2 stem: the staged-window kernel (16-bit types; 40 -> 20x20 and 104 -> 52x52 outputs: partial 16x16 tiles, several tile
+    columns) and the tap-by-tap kernel (fp32 always; 16-bit with VK_NO_STEM_TILE), with the BatchNorm partial sums."""
     dt = DT[dtn]
-    N, S = 2, 64
+    if path == "tap":
+        monkeypatch.setenv("VK_NO_STEM_TILE", "1")
+    else:
+        monkeypatch.delenv("VK_NO_STEM_TILE", raising=False)
+    N = 2
     x = gen(N, 3, S, S, seed=11)
     w = gen(64, 3, 7, 7, seed=12, scale=0.1)
     xd = D(x)
@@ -303,13 +311,19 @@ def test_stem_fwd(dtn):
     wp = torch.zeros(64, 7, 8, 4)
     wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
     wpd = D(wp.reshape(64, 7, 32).to(dt))
-    y = torch.empty((N, S // 2, S // 2, 64), dtype=dt, device=dev())
+    y = torch.full((N, S // 2, S // 2, 64), float("nan"), dtype=dt, device=dev())
     stats = torch.zeros(REPL * 128, dtype=torch.float64, device=dev())
     vk._lib.check(vk.lib().vk_stem_fwd(L_.dtype_code(dt), N, S, S, x4.data_ptr(), wpd.data_ptr(), y.data_ptr(), stats.data_ptr(), st()))
     torch.cuda.synchronize()
     ref = F.conv2d(rnd(x, dt).double(), rnd(w, dt).double(), stride=2, padding=3).float()
-    err = (from_nhwc(y) - ref).abs().max().item()
+    got = from_nhwc(y)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
     assert err <= tol(dt, ref), err
+    sm = stats.cpu().view(REPL, 128).sum(0)
+    yy = got.double()
+    assert torch.allclose(sm[:64], yy.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3 * yy.abs().max().item() * yy[:, 0].numel() ** 0.5)
+    assert torch.allclose(sm[64:], (yy * yy).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
 
 
 # ------------------------------------------------------------------------------------------------ dgrad

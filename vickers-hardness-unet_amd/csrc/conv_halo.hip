@@ -14,6 +14,7 @@
 //     ds_read_b128 for 16 consecutive rows at ANY row offset (tap shifts), no padding.
 //   * 16x16 MFMA tiles, "swapped" orientation, epilogue through LDS with BN partial sums — as conv_igemm.
 #include <stdlib.h>
+#include <string.h>
 
 #include <string>
 #include <type_traits>
@@ -1405,6 +1406,124 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_colp_kernel(cons
 #pragma unroll
     for (int i = 0; i < NPV; ++i) { h_full[i] = h_full_n[i]; h_half[i] = h_half_n[i]; }
   }
+}
+
+// ---- stem: 7x7 stride-2 pad-3 convolution of the NHWC4 input (16-bit types), reference train.py:436 -> encoder.conv1.
+// GEMM view: K = 7 filter rows x 32 (8 columns x 4 channels, the 8th column and the 4th channel are zero weights); the A operand of
+// output pixel j and filter row r is the 64 contiguous bytes of input row 2i + r - 3 that start at pixel 2j - 3.  The tap-by-tap
+// kernel gathered those 64 bytes per pixel and row from L1 / L2 (every input byte 28 times: 1.9 GB through the vector caches for a
+// 67 MB input); here the 37 x 40-pixel input window of a 16 x 16 output tile is staged ONCE (11.8 KB) and the fragments are
+// ds_read_b128 at byte 16 * (j + kg) of the row: consecutive lanes read consecutive 16-byte pieces (conflict-free, lanes with equal
+// j + kg share one).  Global loads are 16-byte vectors of two pixels at even x (never straddle the image edge: the zero padding is
+// the buffer bounds check); each is stored as two 8-byte halves one pixel to the left so that the window of pixel j starts 16-byte
+// aligned.  The 28 weight fragments (7 rows x 4 channel tiles, 1 KB each) are copied to LDS by LDS-DMA in fragment order (lane =
+// kg * 16 + channel: the reads are consecutive 16-byte pieces) while the window loads are in flight — fetched per filter row from
+// L2 they put an L2 round trip in front of every 16 MFMAs (148 -> 126 us only).
+// Wave layout, epilogue and BN statistics are those of the 16x16x64 tile: accumulation order r = 0..6.
+struct StemTile {
+  static constexpr int ROWS = 37, VPR = 20, PITCH = VPR * 16;        // staged rows, 16-byte vectors per row, row pitch
+  static constexpr int A_BYTES = ROWS * PITCH;
+  static constexpr int W_OFF = (A_BYTES + 1023) / 1024 * 1024, W_BYTES = 28 * 1024;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void stem7x7_kernel(const HaloParams p) {
+  using Cfg = ColCfg<T, 16, 64, 4, 1, false>;
+  static_assert(sizeof(T) == 2, "16-bit types: a pixel of the NHWC4 input is 8 bytes");
+  constexpr int NV = (StemTile::ROWS * StemTile::VPR + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bt = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);        // contiguous runs of tiles per XCD
+  const int tx = bt % p.tiles_x;
+  bt /= p.tiles_x;
+  const int ty = bt % p.tiles_y;
+  const int n = bt / p.tiles_y;
+  const int y0 = ty * 16, x0 = tx * 16;
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.s0.ptr, p.s0.bytes);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
+
+  // ---- input window -> registers
+  u32x4_t areg[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + i * 256;
+    const int ry = v / StemTile::VPR, vc = v - ry * StemTile::VPR;
+    const int y = 2 * y0 - 3 + ry, x = 2 * x0 - 4 + 2 * vc;
+    const bool ok = v < StemTile::ROWS * StemTile::VPR && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+    areg[i] = buf_load16(rs0, ok ? (uint32_t)((n * p.Hi + y) * p.Wi + x) * 8u : kOOB);
+  }
+  const int li = lane & 15, kg = lane >> 4;
+  // weight fragment (filter row r, channel tile a) = wp[a * 16 + li][r][kg * 8 ..] of lane kg * 16 + li -> LDS piece 4 r + a
+  typedef __attribute__((address_space(3))) void lds_void;
+  char* const Wl = smem + StemTile::W_OFF;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int pc = wave * 7 + i, r = pc >> 2, a = pc & 3;
+    const uint32_t voff = (uint32_t)((((a * 16 + li) * 7 + r) * 32 + kg * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wl + pc * 1024), 16, voff, 0, 0, 0);
+  }
+  // ---- registers -> LDS, each pixel one slot to the left (the pixel at x = 2 x0 - 4 is not part of any window)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + i * 256;
+    if (v >= StemTile::ROWS * StemTile::VPR) continue;
+    const int ry = v / StemTile::VPR, vc = v - ry * StemTile::VPR;
+    char* row = smem + ry * StemTile::PITCH;
+    if (vc > 0) *reinterpret_cast<u32x2_t*>(row + (2 * vc - 1) * 8) = u32x2_t{areg[i][0], areg[i][1]};
+    *reinterpret_cast<u32x2_t*>(row + (2 * vc) * 8) = u32x2_t{areg[i][2], areg[i][3]};
+  }
+  __syncthreads();                                          // also drains the LDS-DMA (vmcnt(0))
+
+  const int wrow0 = wave * 4;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const char* const xl = smem + (2 * wrow0) * StemTile::PITCH + 16 * (li + kg);
+  const char* const wl = Wl + lane * 16;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    u32x4_t X[4], Wc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) Wc[a] = *reinterpret_cast<const u32x4_t*>(wl + (4 * r + a) * 1024);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) X[b] = *reinterpret_cast<const u32x4_t*>(xl + (2 * b + r) * StemTile::PITCH);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = Mma<T>::run(Wc[a], X[b], acc[a][b]);
+  }
+  __syncthreads();                                          // the epilogue reuses the window's LDS
+  halo_epilogue<T, 16, 64, 4, 4, 256, false>(smem, acc, p, n, y0, x0, 0, wrow0, 0);
+}
+
+int stem_tile_launch(vk_dtype dt, int N, int H, int W, const void* x4, const void* wp, void* y, double* stats, hipStream_t st) {
+  if (dt == VK_F32 || getenv("VK_NO_STEM_TILE")) return VK_ERR_UNSUPPORTED;
+  if ((size_t)N * H * W * 8 >= (1ull << 31)) return VK_ERR_UNSUPPORTED;
+  HaloParams p;
+  memset((void*)&p, 0, sizeof(p));
+  p.s0 = HaloSrc{x4, nullptr, nullptr, 4, 0, 0, (uint32_t)((size_t)N * H * W * 8)};
+  p.w = wp;
+  p.w_bytes = 64u * 7u * 32u * 2u;
+  p.y0 = y;
+  p.ld0 = 64;
+  p.stats = stats;
+  p.N = N; p.H = H / 2; p.W = W / 2; p.K = 64; p.C = 4;
+  p.Hi = H; p.Wi = W;
+  p.tiles_x = (p.W + 15) / 16;
+  p.tiles_y = (p.H + 15) / 16;
+  using Cfg = ColCfg<bf16_t, 16, 64, 4, 1, false>;
+  constexpr int MAIN = StemTile::W_OFF + StemTile::W_BYTES;
+  constexpr int SMEM = MAIN > Cfg::EPI ? MAIN : Cfg::EPI;
+  const dim3 grid((unsigned)(N * p.tiles_y * p.tiles_x));
+  vkh::ProfScope ps("stem_tile_16b", st, 2.0 * (double)N * p.H * p.W * 64.0 * 147.0, ((double)N * H * W * 4.0 + (double)N * p.H * p.W * 64.0) * 2.0);
+  if (dt == VK_BF16) hipLaunchKernelGGL(stem7x7_kernel<bf16_t>, grid, dim3(256), SMEM, st, p);
+  else hipLaunchKernelGGL(stem7x7_kernel<f16_t>, grid, dim3(256), SMEM, st, p);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
 }
 
 // ---- C == 16 (16-bit types): decoder block 4 conv2 and the data gradients whose reduction runs over 16 channels.

@@ -601,10 +601,17 @@ int conv_fwd_impl(const vk_conv_desc* d, const void* w, int packed, void* y, voi
   return dispatch(d->dtype, p, mode, st);
 }
 
+int stem_tile_launch(vk_dtype dt, int N, int H, int W, const void* x4, const void* wp, void* y, double* stats, hipStream_t st);      // conv_halo.hip
+
 int stem_fwd_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void* wp, void* y, double* stats,
                   hipStream_t st) {
   VK_CHECK_ARG(x4 && wp && y, "vk_stem_fwd: null argument");
   VK_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "vk_stem_fwd: H, W must be even");
+  {
+    // 16-bit types: the input window of a 16x16 output tile staged once (stem7x7_kernel); fp32 stays on the tap-by-tap kernel
+    const int rc = stem_tile_launch(dt, N, H, W, x4, wp, y, stats, st);
+    if (rc != VK_ERR_UNSUPPORTED) return rc;
+  }
   const int eb = dt == VK_F32 ? 4 : 2;
   ConvParams p;
   p.s0 = SrcDev{x4, nullptr, nullptr, 4, 0, 0, (uint32_t)((size_t)N * H * W * 4 * eb)};
