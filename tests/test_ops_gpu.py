@@ -473,6 +473,9 @@ def test_conv_dgrad_fused_bn_relu_reduce(dtn, pool2, shape, persist):
 WGRAD_CASES = [
     ("l1", 2, 24, 64, 64, 3, 1, 1),
     ("l2_s2", 2, 24, 64, 128, 3, 2, 1),
+    ("l3_s2_ragged", 1, 26, 128, 256, 3, 2, 1),            # 13 x 13 dz: partial 8 x 16 tiles
+    ("l4_s2", 1, 20, 256, 512, 3, 2, 1),
+    ("s2_wide", 1, 72, 32, 64, 3, 2, 1),                   # three tile columns, one 32-channel chunk
     ("l2_1x1", 2, 24, 64, 128, 1, 2, 0),
     ("l3", 1, 16, 256, 256, 3, 1, 1),
     ("dec3_c2", 1, 40, 32, 32, 3, 1, 1),

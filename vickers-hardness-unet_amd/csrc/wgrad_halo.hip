@@ -34,17 +34,22 @@ struct WhParams {
   const void* dz;
   uint32_t dz_bytes;
   float* dw;
-  int N, H, W, K, C;
+  int N, H, W, K, C;            // H, W: size of dz (= of the input for the stride-1 layers)
+  int Hi, Wi;                   // size of the input V (stride 2: 2 H x 2 W)
   int tiles_x, tiles_y, ntiles, splits;
   int dbg_skip_epilogue;      // timing experiments only (VK_WH_DBG_NOEPI)
   float* slab;                // [splits][K][9][C] partial results (deterministic two-stage reduce) or nullptr (atomics)
 };
 
-template <typename T, int KT, int CT, bool WS, bool TS = false>
+// STR = 2 (the stride-2 3x3 openers of layers 2-4): the (2 * 8 + 1) x 33 input pixels under an 8 x 16 dz tile are staged with odd and
+// even columns in separate planes of every LDS row (slot = row * 34 + (x & 1) * 17 + (x >> 1)), so the 16 pixels of a tile row of
+// tap column s are 16 consecutive slots again; tile row b of filter row r reads halo row 2 b + r.
+template <typename T, int KT, int CT, bool WS, bool TS = false, int STR = 1>
 struct WhCfg {
   using Tr = ElemTraits<T>;
   static constexpr int EB = Tr::kBytes, VE = Tr::kVec;
-  static constexpr int TH = 8, PX = 128, HPIX = 10 * 18;
+  static constexpr int HWI = STR == 1 ? 18 : 33, HRS = STR == 1 ? 18 : 34, HHI = STR == 1 ? 10 : 17;      // staged columns, slots per row, rows
+  static constexpr int TH = 8, PX = 128, HPIX = HHI * HWI;
   static constexpr int NT = TS ? 512 : 256;                    // TS: two wave groups share the staged tiles, taps 0-4 / 5-8
   static constexpr int NTAP = TS ? 5 : 9;                      // accumulated taps per wave
   static constexpr int ZV = KT / VE, VV = CT / VE;
@@ -52,7 +57,7 @@ struct WhCfg {
   static constexpr int zpad(int ch) { return EB == 2 ? (((ch * 2 / 32) % 2 == 0) ? 32 : 0) : ((ch % 32 == 0) ? 64 : 0); }
   static constexpr int ZSB = KT * EB + zpad(KT);
   static constexpr int VSB = CT * EB + zpad(CT);
-  static constexpr int STAGE = PX * ZSB + HPIX * VSB;
+  static constexpr int STAGE = PX * ZSB + HHI * HRS * VSB;
   static constexpr int WK = WS ? KT : KT / 2, WC = WS ? CT : CT / 2;
   static constexpr int TK = WK / 16, TCc = WC / 16;
   static constexpr int RED = KT * CT * 9 * 4;      // fp32 [KT][9][CT] output tile staged for coalesced stores
@@ -60,11 +65,14 @@ struct WhCfg {
   static constexpr int SMEM = (NSTAGE * STAGE > RED) ? NSTAGE * STAGE : RED;
   static_assert(TK >= 1 && TCc >= 1 && TK * TCc * NTAP <= 36, "accumulator budget");
   static_assert(!(TS && WS), "tap split is for the 2x2 wave layout");
+  static_assert(STR == 1 || (STR == 2 && EB == 2 && !WS), "stride 2: 16-bit types, 2x2 wave layout");
+  static_assert(NSTAGE * STAGE <= 160 * 1024 && RED <= 160 * 1024, "LDS image exceeds the 160 KiB of a CU");
 };
 
-template <typename T, int KT, int CT, bool WS, bool TS>
+template <typename T, int KT, int CT, bool WS, bool TS, int STR = 1>
 __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhParams p) {
-  using Cfg = WhCfg<T, KT, CT, WS, TS>;
+  using Cfg = WhCfg<T, KT, CT, WS, TS, STR>;
+  constexpr int HWI = Cfg::HWI, HRS = Cfg::HRS;
   constexpr int NT = Cfg::NT, NTAP = Cfg::NTAP;
   constexpr int EB = Cfg::EB, VE = Cfg::VE, PX = Cfg::PX, HPIX = Cfg::HPIX, ZV = Cfg::ZV, VV = Cfg::VV;
   constexpr int ZPASS = Cfg::ZPASS, VPASS = Cfg::VPASS, ZSB = Cfg::ZSB, VSB = Cfg::VSB, STAGE = Cfg::STAGE;
@@ -80,8 +88,8 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
   const int cl0 = first ? c0 : c0 - p.s0.C;
   const __amdgpu_buffer_rsrc_t rsv = make_rsrc(sd.ptr, sd.bytes);
   const __amdgpu_buffer_rsrc_t rsz = make_rsrc(p.dz, p.dz_bytes);
-  const int up = sd.up;
-  const int Hs = p.H >> up, Ws = p.W >> up;
+  const int up = STR == 1 ? sd.up : 0;
+  const int Hs = p.Hi >> up, Ws = p.Wi >> up;
   const bool affine = sd.scale != nullptr;
   const bool relu = sd.relu != 0;
 
@@ -96,7 +104,9 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
 
   // staging registers: one set (tile t+1 in flight under the MFMAs of tile t) or, in the small-channel WS configurations whose
   // tiles are a few MFMAs long, two sets (tiles t+1 and t+2 in flight: an HBM round trip is longer than one tile's work)
-  constexpr int DEPTH = (WS || KT <= 32) ? 2 : 1;
+  // (also the stride-2 configuration: 36 MFMAs per wave and tile against 52 KB of staging)
+  // measured and rejected (r02): two sets for the 64x64 tap-split configuration as well (layer 2-4 / dec0 shapes unchanged within 1 %)
+  constexpr int DEPTH = (WS || KT <= 32 || STR == 2) ? 2 : 1;
   // measured and rejected (r02): the next tile's LDS writes between the 32-pixel steps instead of after the last one — L1 / L2 shapes
   // 60 -> 66 us (the writes then wait for HBM loads that the remaining steps used to cover), others unchanged
   constexpr bool STORE_MID = false;
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
   for (int i = 0; i < VPASS; ++i) {
     const int v = tid + i * NT;
     const int hp = v / VV, vec = v % VV;
-    const int hy = hp / 18, hx = hp - hy * 18;
+    const int hy = hp / HWI, hx = hp - hy * HWI;
     const bool ok = v < HPIX * VV;
     v_rel[i] = (((hy - 1) >> up) * Ws + ((hx - 1) >> up)) * sd.C + cl0 + vec * VE;     // tile origins are even
     v_yx[i] = ok ? ((hy << 8) | hx) : -1;
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
     const int n = tt / p.tiles_y;
     const int y0 = ty * 8, x0 = tx * 16;
     const int zbase = ((n * p.H + y0) * p.W + x0) * p.K;                                // block-uniform
-    const int vbase = ((n * Hs + (y0 >> up)) * Ws + (x0 >> up)) * sd.C;
+    const int vbase = ((n * Hs + ((STR * y0) >> up)) * Ws + ((STR * x0) >> up)) * sd.C;
 #pragma unroll
     for (int i = 0; i < ZPASS; ++i) {
       const bool ok = z_yx[i] >= 0 && y0 + (z_yx[i] >> 8) < p.H && x0 + (z_yx[i] & 255) < p.W;
@@ -141,8 +151,8 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
     vmask = 0;
 #pragma unroll
     for (int i = 0; i < VPASS; ++i) {
-      const int y = y0 - 1 + (v_yx[i] >> 8), x = x0 - 1 + (v_yx[i] & 255);
-      const bool ok = v_yx[i] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const int y = STR * y0 - 1 + (v_yx[i] >> 8), x = STR * x0 - 1 + (v_yx[i] & 255);
+      const bool ok = v_yx[i] >= 0 && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
       vreg[i] = buf_load16(rsv, ok ? (uint32_t)(vbase + v_rel[i]) * (uint32_t)EB : kOOB);
       vmask |= (ok ? 1u : 0u) << i;
     }
@@ -164,7 +174,12 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
         x = AffineRelu<T>::run(x, sc, sh, relu);
         if (!((vmask >> i) & 1u)) x = u32x4_t{0, 0, 0, 0};
       }
-      if (v < HPIX * VV) *reinterpret_cast<u32x4_t*>(Vs + (v / VV) * VSB + (v % VV) * 16) = x;
+      int slot = v / VV;
+      if (STR == 2) {                                      // odd / even input columns in separate planes of the row
+        const int hy = slot / HWI, hx = slot - hy * HWI;
+        slot = hy * HRS + (hx & 1) * 17 + (hx >> 1);
+      }
+      if (v < HPIX * VV) *reinterpret_cast<u32x4_t*>(Vs + slot * VSB + (v % VV) * 16) = x;
     }
   };
 
@@ -212,9 +227,9 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
           u32x4_t vf[TCc];
 #pragma unroll
           for (int b = 0; b < TCc; ++b) {
-            const char* b0 = Vl + ((2 * ks + r) * 18 + s) * VSB + (b * 16) * 2;
+            const char* b0 = Vl + (STR == 1 ? (2 * ks + r) * 18 + s : (4 * ks + r) * HRS + (s & 1) * 17 + (s >> 1)) * VSB + (b * 16) * 2;
             const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0));
-            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + 18 * VSB));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + STR * HRS * VSB));
             const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
             vf[b] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
           }
@@ -394,9 +409,9 @@ __global__ __launch_bounds__(256) void k_wgrad_slab_reduce(size_t n4, int splits
 static int wh_max_combo() { const char* e = getenv("VK_WH_MAXCOMBO"); return e ? atoi(e) : 64; }
 static int wh_min_blocks() { const char* e = getenv("VK_WH_MINBLOCKS"); return e ? atoi(e) : 160; }
 
-template <typename T, int KT, int CT, bool WS, bool TS = false>
+template <typename T, int KT, int CT, bool WS, bool TS = false, int STR = 1>
 static int launch_wh(WhParams p, size_t slab_bytes, hipStream_t st) {
-  using Cfg = WhCfg<T, KT, CT, WS, TS>;
+  using Cfg = WhCfg<T, KT, CT, WS, TS, STR>;
   p.tiles_x = (p.W + 15) / 16;
   p.tiles_y = (p.H + 7) / 8;
   p.ntiles = p.N * p.tiles_y * p.tiles_x;
@@ -416,15 +431,16 @@ static int launch_wh(WhParams p, size_t slab_bytes, hipStream_t st) {
   dim3 grid(kt, ct, splits);
   static bool attr_done = false;
   if (!attr_done && Cfg::SMEM > 64 * 1024) {
-    VK_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<T, KT, CT, WS, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<T, KT, CT, WS, TS, STR>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
     attr_done = true;
   }
   {
-    static const std::string tag = std::string("wgrad_halo_") + (sizeof(T) == 4 ? "f32" : "16b") + "_" + std::to_string(KT) + "x" + std::to_string(CT) + (TS ? "ts" : "");
-    const double bytes = (double)p.N * p.H * p.W * (p.C + p.K) * sizeof(T) + 9.0 * p.K * p.C * 4.0;
+    static const std::string tag = std::string("wgrad_halo_") + (sizeof(T) == 4 ? "f32" : "16b") + "_" + std::to_string(KT) + "x" + std::to_string(CT) + (TS ? "ts" : "") +
+                                   (STR == 2 ? "_s2" : "");
+    const double bytes = ((double)p.N * p.Hi * p.Wi * p.C + (double)p.N * p.H * p.W * p.K) * sizeof(T) + 9.0 * p.K * p.C * 4.0;
     const std::string dtag = getenv("VK_PROF_DETAIL") ? tag + ":H" + std::to_string(p.H) + "_K" + std::to_string(p.K) + "_C" + std::to_string(p.C) + "_s" + std::to_string(splits) : tag;
     vkh::ProfScope ps(dtag.c_str(), st, 2.0 * (double)p.N * p.H * p.W * p.K * 9.0 * p.C, bytes);
-    hipLaunchKernelGGL((wgrad_halo_kernel<T, KT, CT, WS, TS>), grid, dim3(Cfg::NT), Cfg::SMEM, st, p);
+    hipLaunchKernelGGL((wgrad_halo_kernel<T, KT, CT, WS, TS, STR>), grid, dim3(Cfg::NT), Cfg::SMEM, st, p);
   }
   if (p.slab) {
     const size_t n4 = (size_t)p.K * 9 * p.C / 4;
@@ -461,12 +477,16 @@ static int wh_select(const WhParams& p, int cgran, size_t slab_bytes, hipStream_
 
 // returns VK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the tap-by-tap kernel)
 int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, void* workspace, size_t workspace_bytes, hipStream_t st) {
-  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->H != d->Ho || d->W != d->Wo) return VK_ERR_UNSUPPORTED;
+  // stride 2 (16-bit types): the openers of layers 2-4 — materialised single source, reduction chunks of 32 channels
+  const bool s2 = d->stride == 2 && d->dtype != VK_F32 && d->H == 2 * d->Ho && d->W == 2 * d->Wo && !d->src1.ptr && !d->src0.up && d->src0.C % 32 == 0 &&
+                  d->K >= 64 && !getenv("VK_NO_S2_TILE");
+  if (d->R != 3 || d->S != 3 || d->pad != 1) return VK_ERR_UNSUPPORTED;
+  if (!s2 && (d->stride != 1 || d->H != d->Ho || d->W != d->Wo)) return VK_ERR_UNSUPPORTED;
   if (getenv("VK_NO_WGRAD_HALO")) return VK_ERR_UNSUPPORTED;
   const int eb = d->dtype == VK_F32 ? 4 : 2;
   const int C = d->src0.C + (d->src1.ptr ? d->src1.C : 0);
   if (d->K % 16 || d->src0.C % 16 || (d->src1.ptr && (d->src1.C % 16 || d->src1.up))) return VK_ERR_UNSUPPORTED;
-  if ((size_t)d->N * d->H * d->W * C * eb >= (1ull << 31) || (size_t)d->N * d->H * d->W * d->K * eb >= (1ull << 31)) return VK_ERR_UNSUPPORTED;
+  if ((size_t)d->N * d->H * d->W * C * eb >= (1ull << 31) || (size_t)d->N * d->Ho * d->Wo * d->K * eb >= (1ull << 31)) return VK_ERR_UNSUPPORTED;
   int cgran = 64;
   while (cgran > 16 && (d->src0.C % cgran || (d->src1.ptr && d->src1.C % cgran))) cgran >>= 1;
   WhParams p;
@@ -480,12 +500,17 @@ int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, void* works
   if (d->src1.ptr) p.s1 = mk(d->src1);
   else p.s1 = WhSrc{nullptr, nullptr, nullptr, 0, 0, 0, 0u};
   p.dz = dz;
-  p.dz_bytes = (uint32_t)((size_t)d->N * d->H * d->W * d->K * eb);
+  p.dz_bytes = (uint32_t)((size_t)d->N * d->Ho * d->Wo * d->K * eb);
   p.dw = dw;
-  p.N = d->N; p.H = d->H; p.W = d->W; p.K = d->K; p.C = C;
+  p.N = d->N; p.H = d->Ho; p.W = d->Wo; p.K = d->K; p.C = C;
+  p.Hi = d->H; p.Wi = d->W;
   p.tiles_x = p.tiles_y = p.ntiles = p.splits = 0;
   p.dbg_skip_epilogue = 0;
   p.slab = (float*)workspace;
+  if (s2) {
+    if (d->dtype == VK_BF16) return launch_wh<bf16_t, 64, 32, false, true, 2>(p, workspace_bytes, st);
+    return launch_wh<f16_t, 64, 32, false, true, 2>(p, workspace_bytes, st);
+  }
   switch (d->dtype) {
     case VK_F32: return wh_select<float>(p, cgran, workspace_bytes, st);
     case VK_BF16: return wh_select<bf16_t>(p, cgran, workspace_bytes, st);
