@@ -26,10 +26,12 @@ def family(name):
     m = re.search(r"conv3x3_s2dg_kernel<vk::(\w+), \d+, (\d+)", name)
     if m:
         return f"s2dg_{'f32' if m.group(1) == 'float' else '16b'}_bn{m.group(2)}"
-    m = re.search(r"wgrad_halo_kernel<vk::(\w+), (\d+), (\d+), (\w+), (\w+)>", name)
+    m = re.search(r"wgrad_halo_kernel<vk::(\w+), (\d+), (\d+), (\w+), (\w+)(?:, (\d+))?>", name)
     if m:
-        t, kt, ct, ws, ts = m.groups()
-        return f"wgrad_halo_{'f32' if t == 'float' else '16b'}_{kt}x{ct}{'ts' if ts == 'true' else ''}"
+        t, kt, ct, ws, ts, stride = m.groups()
+        return f"wgrad_halo_{'f32' if t == 'float' else '16b'}_{kt}x{ct}{'ts' if ts == 'true' else ''}" + ("_s2" if stride == "2" else "")
+    if "stem7x7_kernel" in name:
+        return "stem_tile_16b"
     m = re.search(r"vk::(\w+)", name)
     return m.group(1) if m else name[:40]
 
