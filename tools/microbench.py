@@ -19,6 +19,8 @@ LAYERS = {
     "L1": (128, [(64, 0)], 64), "L2": (64, [(128, 0)], 128), "L3": (32, [(256, 0)], 256), "L4": (16, [(512, 0)], 512),
     "D0c1": (32, [(512, 1), (256, 0)], 256), "D1c1": (64, [(256, 1), (128, 0)], 128), "D2c1": (128, [(128, 1), (64, 0)], 64),
     "D3c1": (256, [(64, 1), (64, 0)], 32), "D3c2": (256, [(32, 0)], 32), "D4c1": (512, [(32, 1)], 16), "D4c2": (512, [(16, 0)], 16),
+    # the shapes of the two concat data gradients with a one- / two-chunk reduction (forward op of the same kernel class)
+    "D3c1g": (256, [(32, 0)], 128), "D2c1g": (128, [(64, 0)], 192),
 }
 
 

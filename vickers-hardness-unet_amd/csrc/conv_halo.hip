@@ -547,7 +547,10 @@ struct ColCfg {
   static constexpr int TP = TH / WGM, TC = BN / WGN / 16;
   static constexpr int NX = STR * (TP - 1) + 3;                     // halo rows a wave reads per stage
   static constexpr int ESB = BN * EB + 16;
-  static constexpr int MAIN = NA * A_BYTES + 2 * B_BYTES;
+  // weight stage buffers: two (double buffering); three for the small channel tiles, so that a ONE-chunk reduction (decoder blocks 3/4:
+  // C = 32) gets the weights of all three filter columns in one LDS-DMA round and runs its stages without a barrier between them
+  static constexpr int NB = (BN <= 64 && STR == 1) ? 3 : 2;
+  static constexpr int MAIN = NA * A_BYTES + NB * B_BYTES;
   static constexpr int ESLOTS = (BN / VE > 16) ? NW * 4 / (BN / VE / 16) : NW * 4;
   static constexpr int EPI = BM * ESB + ESLOTS * BN * 2 * 4;     // + [wave x 16-lane row][channel][2] partial sums
   static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
@@ -725,12 +728,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
   const int c_begin = (int)((long)p.nchunks * blockIdx.z / ksp), c_end = (int)((long)p.nchunks * (blockIdx.z + 1) / ksp);
   load_halo(c_begin);
   dma_b(c_begin, 0, 0);
+  const bool one_chunk = Cfg::NB == 3 && c_end - c_begin == 1 && !p.dbg;
+  if (one_chunk) {                                        // all three filter columns now: the stages need no barrier between them
+    dma_b(c_begin, 1, 1);
+    dma_b(c_begin, 2, 2);
+  }
   store_halo(Abuf);
   __syncthreads();                                        // also drains the LDS-DMA (vmcnt(0))
   VK_T(t_pro)
 
   int st = 0;
-  for (int cc = c_begin; cc < c_end; ++cc) {
+  if (one_chunk) {
+    const char* A = Abuf + a_lane;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) compute(A + (STR == 1 ? s : (s & 1) * 17 + (s >> 1)) * APS, Bbuf + s * Cfg::B_BYTES + b_lane);
+    __syncthreads();                                      // the epilogue reuses the operand buffers
+    st = 3;
+  }
+  for (int cc = c_begin; cc < c_end && !one_chunk; ++cc) {
     const bool next_chunk = cc + 1 < c_end;
     const char* A = Abuf + (ADB ? ((cc - c_begin) & 1) * Cfg::A_BYTES : 0) + a_lane;
     char* const Anext = Abuf + (ADB ? ((cc - c_begin + 1) & 1) * Cfg::A_BYTES : 0);
@@ -1865,7 +1880,9 @@ static int col_select(const HaloParams& p, hipStream_t st) {
     if (alt == 1) return launch_col<T, 16, 128, 2, 2, true, 1>(p, st);
     // a short reduction onto a channel count that is not a multiple of 128 (the concat gradient of decoder block 2: 64 -> 192):
     // 64-channel tiles waste no half-empty channel tile (201 -> 156 us stand-alone)
-    if (alt == 8 || (alt == 0 && p.nchunks <= 2 && p.K % 128 != 0)) return launch_small<T, 64>(p, st);
+    // ... and a ONE-chunk reduction onto 128+ channels (the concat gradient of decoder block 3: 32 -> 128) as well: the 64-channel
+    // tile gets all three filter columns in one LDS-DMA round (346 -> 300 us stand-alone)
+    if (alt == 8 || (alt == 0 && p.nchunks <= 2 && p.K % 128 != 0) || (alt == 0 && p.nchunks == 1)) return launch_small<T, 64>(p, st);
     // a reduction of one or two channel chunks (the concat gradients of decoder blocks 2/3: HBM / epilogue-bound, thousands of
     // tiles): the 4-wave 8x16x128 tile, two workgroups per CU
     if (alt == 3 || (alt != 2 && alt != 7 && p.nchunks <= 2)) return launch_col<T, 8, 128, 2, 2, false, 2>(p, st);
