@@ -254,6 +254,27 @@ def main():
                                               f"launch of the kernel symbol, FETCH doubled for gfx950), measured on kernel sources {here[:12]} = this tree")
             except Exception:
                 pass
+            if roof["bound"] == "mfma" and "f32" not in tag:
+                # what the matrix pipes deliver on THIS box at the clock it sustains under load: a bare loop of independent 16x16x32
+                # bf16 MFMAs on register operands, two waves on every SIMD, ~2 ms (vk_probe_mfma_rate) — context for `frac`, which
+                # stays priced against the guide's 2.5 PFLOP/s
+                try:
+                    import ctypes as _C
+                    sink = torch.zeros(4, device=dev)
+                    fl = _C.c_double(0.0)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    st_ = torch.cuda.current_stream().cuda_stream
+                    vk._lib.check(L.vk_probe_mfma_rate(2000, 2, sink.data_ptr(), _C.byref(fl), st_), "vk_probe_mfma_rate")   # warm-up / clock ramp
+                    e0.record()
+                    vk._lib.check(L.vk_probe_mfma_rate(20000, 2, sink.data_ptr(), _C.byref(fl), st_), "vk_probe_mfma_rate")
+                    e1.record()
+                    torch.cuda.synchronize()
+                    sustained = fl.value / (e0.elapsed_time(e1) * 1e-3)
+                    roof["mfma_sustained_on_this_box"] = {"tflops": round(sustained / 1e12, 1), "frac_of_peak": round(sustained / peak, 4),
+                                                          "kernel_frac_of_sustained": round(ach / sustained, 4),
+                                                          "how": "bare v_mfma_f32_16x16x32_bf16 loop on pseudo-random register operands, 2 waves per SIMD on every CU, ~2 ms"}
+                except Exception as ex_:      # a measurement aid: never fails the bench line
+                    roof["mfma_sustained_on_this_box"] = {"error": str(ex_)[:200]}
             tot = sum(v["ms"] for v in table.values())
             roof["share_of_gpu_time"] = round(r["ms"] / tot, 3)
             roof["all_kernels_ms_per_step"] = {k: round(v["ms"] / args.prof_steps, 3) for k, v in

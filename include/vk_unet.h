@@ -55,6 +55,10 @@ int vk_version(void);
 const char* vk_last_error_string(void);
 /* 1 if the code object for gfx950 is present in this build (always true for a product build) */
 int vk_has_gfx950_code(void);
+/* Measurement aid (bench.py): a bare loop of independent v_mfma_f32_16x16x32_bf16 on register operands, `waves_per_simd` waves on
+ * every SIMD of the chip, `iters` x 8 MFMAs each — what the matrix pipes deliver at the clock the chip sustains under that load.
+ * FLOPs issued = *flops_out (when not null); time it with events on `stream`.  sink: 4 floats of device scratch. */
+int vk_probe_mfma_rate(int iters, int waves_per_simd, float* sink, double* flops_out, void* stream);
 
 /* Per-launch timing (off by default): while enabled every launch made through this library is bracketed
  * by two hipEvents on its own stream.  vk_prof_collect synchronises those events and writes one line per

@@ -74,6 +74,7 @@ SIGNATURES = {
     "vk_version": (ci, []),
     "vk_last_error_string": (C.c_char_p, []),
     "vk_has_gfx950_code": (ci, []),
+    "vk_probe_mfma_rate": (ci, [ci, ci, vp, P(C.c_double), vp]),
     "vk_debug_set_stamp_buffer": (ci, [vp]),
     "vk_prof_enable": (ci, [ci]),
     "vk_prof_collect": (ci, [C.c_char_p, sz]),

@@ -111,6 +111,33 @@ namespace vk {
 
 __global__ void k_probe() {}
 
+// bare MFMA loop: eight independent accumulator tiles per wave, operands in registers (vk_probe_mfma_rate)
+__global__ __launch_bounds__(256) void k_mfma_rate(int iters, float* sink) {
+  f32x4_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // pseudo-random bf16 operands in +-[0.25, 1) per lane (random signs and mantissas: the data-dependent power of a real GEMM, sums stay
+  // bounded) — on constant operands the same loop runs 94 % of the 2.5 PFLOP/s
+  auto rnd = [](uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (x & 0x807F807Fu) | 0x3E803E80u | ((x >> 7) & 0x01000100u);
+  };
+  const uint32_t seed = (blockIdx.x * 256u + threadIdx.x) * 8u;
+  const u32x4_t a = u32x4_t{rnd(seed), rnd(seed + 1), rnd(seed + 2), rnd(seed + 3)};
+  const u32x4_t b = u32x4_t{rnd(seed + 4), rnd(seed + 5), rnd(seed + 6), rnd(seed + 7)};
+  // inline assembly on fixed VGPR accumulators: the builtin form lets the register allocator rotate the loop-carried tiles through
+  // AGPRs (a dozen v_accvgpr moves per iteration: the loop then measures those, 1.24 PFLOP/s)
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (t == 123.456f) sink[0] = t;                           // keeps the loop alive
+}
+
 // ---------------------------------------------------------------- weight packing kernels
 struct PackEntry {
   int64_t src, dst;     // element offsets: flat params / dgrad arena
@@ -637,6 +664,18 @@ int run_conv(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, int train
 extern "C" int vk_has_gfx950_code(void) {
   hipFuncAttributes a;
   return hipFuncGetAttributes(&a, (const void*)vk::k_probe) == hipSuccess ? 1 : 0;
+}
+
+extern "C" int vk_probe_mfma_rate(int iters, int waves_per_simd, float* sink, double* flops_out, void* stream) {
+  VK_CHECK_ARG(iters >= 1 && waves_per_simd >= 1 && waves_per_simd <= 8 && sink, "vk_probe_mfma_rate: bad argument");
+  int dev = 0, cus = 0;
+  VK_CHECK_HIP(hipGetDevice(&dev));
+  VK_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int blocks = cus * waves_per_simd;                  // 256 threads = one wave per SIMD of a CU
+  if (flops_out) *flops_out = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16.0 * 16.0 * 32.0;
+  hipLaunchKernelGGL(vk::k_mfma_rate, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
 }
 
 extern "C" int vk_unet_create(const vk_unet_config* cfg, vk_unet** out) {
