@@ -81,17 +81,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     vk = importlib.import_module("vickers-hardness-unet_amd")
-    from oracle import unet_oracle as O      # synthetic data generator + (rank 0) CPU baseline only
 
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     N, S = args.batch, args.size
 
-    O.set_seed(42)
+    vk.seed_everything(42)
     model = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev)
     opt = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
     if world > 1 or force_dist:
         vk.make_data_parallel(model, opt, force=force_dist)
-    x, y = O.synthetic_batch(N, S, seed=1234 + rank)      # rank r owns images [r*N, (r+1)*N)
+    x, y = vk.synthetic_batch(N, S, seed=1234 + rank)      # rank r owns images [r*N, (r+1)*N)
     x, y = x.to(dev), y.to(dev)
     _log(f"rank {rank}/{world}: model + data resident on {torch.cuda.get_device_name(dev)}")
 
@@ -242,9 +241,8 @@ def main():
                 roof["kernel_symbol"] = (f"vk::conv3x3_{m_.group(1)}_kernel<{'float' if m_.group(2) == 'f32' else ('vk::bf16_t' if args.dtype == 'bf16' else 'vk::f16_t')}, {m_.group(3)}, {m_.group(4)}, ...> "
                                          f"({m_.group(5)} waves; forward and data-gradient launches)")
             try:
-                tpath = ROOT / "profiles" / "r02" / "traffic.json"
-                tj = json.load(open(tpath))
                 here = kernel_source_hash()
+                tpath, tj = latest_traffic(here)
                 if tj.get("_src_sha256") != here:
                     roof["traffic_source"] = (f"{tpath.relative_to(ROOT)} was measured on kernel sources {str(tj.get('_src_sha256'))[:12]}, "
                                               f"this tree is {here[:12]}: stale, not reported")
@@ -284,6 +282,7 @@ def main():
     cpu = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import unet_oracle as O      # the checker: CPU baseline + parity leg only (never the thing measured)
         cores = _usable_cores()
         torch.set_num_threads(cores)
         _log(f"cpu baseline on {cores} threads ...")
@@ -389,6 +388,19 @@ def kernel_source_hash() -> str:
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()
+
+
+def latest_traffic(src_hash):
+    """The committed PMC traffic measurement to quote: the newest profiles/rNN/traffic.json whose source stamp matches this tree,
+    else the newest one at all (reported as stale by the caller)."""
+    cands = sorted((ROOT / "profiles").glob("r[0-9][0-9]/traffic.json"), reverse=True)
+    loaded = [(p, json.load(open(p))) for p in cands]
+    for p, tj in loaded:
+        if tj.get("_src_sha256") == src_hash:
+            return p, tj
+    if not loaded:
+        raise FileNotFoundError("no profiles/rNN/traffic.json")
+    return loaded[0]
 
 
 def _log(msg):

@@ -9,6 +9,7 @@
  *   vk_unet_forward ........................... model(x)                     train.py:436, 510, 693; infer_pth_gui.py:51
  *   vk_unet_loss .............................. bce(logits,y)+dice(logits,y) train.py:438, 513 (600-601)
  *   vk_unet_backward .......................... loss.backward()              train.py:443, 448
+ *   vk_seg_metrics ............................ dice_coef / iou_coef (validate) train.py:230-281, 518-522
  *   vk_adamw_step ............................. optimizer.step()/zero_grad   train.py:428, 449 (606)
  *   vk_amp_check_inf / vk_amp_unscale_check /
  *   vk_adamw_step_amp ......................... GradScaler unscale + inf check + skipped step  train.py:441-445 (610-611)
@@ -59,6 +60,14 @@ int vk_has_gfx950_code(void);
  * every SIMD of the chip, `iters` x 8 MFMAs each — what the matrix pipes deliver at the clock the chip sustains under that load.
  * FLOPs issued = *flops_out (when not null); time it with events on `stream`.  sink: 4 floats of device scratch. */
 int vk_probe_mfma_rate(int iters, int waves_per_simd, float* sink, double* flops_out, void* stream);
+/* Measurement aid (tests/diag/cu_hold.py): occupy compute units the way a communication library's channel kernels do while a step
+ * runs on another stream.  Launches `workgroups` workgroups of `threads` threads (64..1024) with `lds_bytes` of LDS each
+ * (lds_bytes = 163840 takes a whole CU: no tile kernel fits beside it; a small value lets other workgroups co-reside and only
+ * competes for issue slots / memory queues) that spin for `microseconds` of wall time (s_memrealtime deadline: every wave exits by
+ * itself) and, when `traffic` != 0, keep streaming 16-byte loads from it (traffic_bytes, a power of two >= 64 KiB) meanwhile.
+ * sink: 4 floats of device scratch. */
+int vk_debug_hold_cus(int workgroups, int threads, int lds_bytes, int microseconds, const void* traffic, size_t traffic_bytes,
+                      float* sink, void* stream);
 
 /* Per-launch timing (off by default): while enabled every launch made through this library is bracketed
  * by two hipEvents on its own stream.  vk_prof_collect synchronises those events and writes one line per
@@ -322,6 +331,17 @@ int vk_head_bwd_fused(vk_dtype dtype, int N, int H, int W, const vk_src* src, co
  * dlogits (optional) = grad_scale * d(loss_out[0])/dlogits. */
 int vk_bce_dice_loss(size_t count, const float* logits, const float* target, double* sums, float* loss_out,
                      float* dlogits, float grad_scale, float w_bce, float w_dice, void* stream);
+
+/* Thresholded Dice / IoU of the reference's validate() (train.py:230-255 `dice_coef`, :259-281 `iou_coef`, :518-522):
+ * per image i of `per_image` elements, pred = (p > threshold) as 0/1, I = sum pred*t, P = sum pred, T = sum t;
+ * dice_i = (2 I + eps) / (P + T + eps), iou_i = (I + eps) / (P + T - I + eps) in fp32.
+ * pred: probabilities, or logits when from_logits != 0 (then p = 1 / (1 + expf(-x)) first).
+ * out (device, 2 + 2 n_images floats): [0] mean dice, [1] mean iou, [2 + 2i], [3 + 2i] = image i.
+ * workspace: vk_seg_metrics_workspace_bytes(n_images) of 8-byte aligned device scratch; afterwards it holds the
+ * fp64 sums {I, P, T} per image.  One pass over both tensors + one single-workgroup launch; bit-reproducible for 0/1 targets. */
+size_t vk_seg_metrics_workspace_bytes(int n_images);
+int vk_seg_metrics(int n_images, size_t per_image, const float* pred, const float* target, int from_logits, float threshold,
+                   float eps, void* workspace, size_t workspace_bytes, float* out, void* stream);
 
 /* AdamW (decoupled decay) over a flat fp32 parameter buffer; optionally emits the 16-bit working copy.
  * inv_scale multiplies the gradient first (GradScaler unscale / data-parallel averaging).

@@ -23,7 +23,7 @@ batches = [(x[i:i + 2], y[i:i + 2]) for i in (0, 2, 4)]
 O.set_seed(42); model = vk.Unet(encoder_weights=None).to("cuda:0")
 opt = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
 scaler = vk.GradScaler("cuda", enabled=True)
-lg = [vk.train_one_epoch(model, [(xb, yb, ["a", "b"])], opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler) for xb, yb in batches]
+lg = [O.train_one_epoch(model, [(xb, yb, ["a", "b"])], opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler) for xb, yb in batches]
 print("ENGINE", " ".join(f"{v:.6f}" for v in lg))
 '''
 

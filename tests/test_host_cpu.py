@@ -165,3 +165,28 @@ def test_optimizer_state_dict_is_not_mutated_and_amp_protocol_declared(vk):
     assert set(sd) == keys and "fused" in sd
     assert opt2.step_count == 7 and float(opt2._m[0]) == 0.25 and float(opt2._v[-1]) == 0.5
     assert opt2.state_dict()["fused"]["step"] == 7
+
+
+def test_synthetic_matches_oracle(vk, oracle):
+    """bench.py's GPU leg takes its inputs from the package (vk.synthetic_batch / vk.seed_everything), the CPU-baseline and every
+    parity test from the oracle: both generators must draw the same numbers."""
+    for n, s, seed in ((2, 64, 1234), (3, 96, 1235), (1, 32, 7)):
+        xa, ya = vk.synthetic_batch(n, s, seed=seed)
+        xb, yb = oracle.synthetic_batch(n, s, seed=seed)
+        assert torch.equal(xa, xb) and torch.equal(ya, yb)
+        fg = ya.mean(dim=(1, 2, 3))
+        assert (fg > 0.005).all() and (fg < 0.13).all()          # 1-12 % foreground, never empty
+    vk.seed_everything(42); a = torch.rand(3)
+    oracle.set_seed(42); b = torch.rand(3)
+    assert torch.equal(a, b)
+    vk.seed_everything(42); m1 = vk.Unet(encoder_weights=None)
+    oracle.set_seed(42); m2 = vk.Unet(encoder_weights=None)
+    assert torch.equal(m1.flat_params, m2.flat_params)
+
+
+def test_package_holds_no_reference_loop(vk):
+    """The epoch loop and the metric definitions are the reference's own code and stay on the user's side:
+    the package exports device kernels, not a restated train.py."""
+    assert not hasattr(vk, "train_one_epoch") and not hasattr(vk, "validate")
+    assert not (ROOT / "vickers-hardness-unet_amd" / "train.py").exists()
+    assert not (ROOT / "vickers-hardness-unet_amd" / "metrics.py").exists()

@@ -59,7 +59,8 @@ def test_eval_logits_fp32(pair, n, s):
     po, pg = torch.sigmoid(lo), torch.sigmoid(lg)
     assert abs(O.iou_coef(pg, y) - O.iou_coef(po, y)) <= 1e-4
     assert abs(O.dice_coef(pg, y) - O.dice_coef(po, y)) <= 1e-4
-    assert abs(vk.iou_coef(pg.to(dev()), y.to(dev())) - O.iou_coef(pg, y)) <= 1e-6
+    assert abs(vk.iou_coef(pg.to(dev()), y.to(dev())) - O.iou_coef(pg, y)) <= 1e-6       # device metric kernel (vk_seg_metrics)
+    assert abs(vk.dice_coef(pg.to(dev()), y.to(dev())) - O.dice_coef(pg, y)) <= 1e-6
 
 
 def _engine_relu_masks(ref, model, n, s):
@@ -274,10 +275,10 @@ def test_reference_style_epoch_with_amp(pair):
     scaler = torch.amp.GradScaler("cuda", enabled=True)
     x, y = O.synthetic_batch(4, 64, seed=11)
     loader = [(x[:2], y[:2], ["a", "b"]), (x[2:], y[2:], ["c", "d"])]
-    l1 = vk.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
-    l2 = vk.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
+    l1 = O.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
+    l2 = O.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
     assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1 + 0.05
-    vl, vd, vi = vk.validate(model, loader, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda")
+    vl, vd, vi = O.validate_epoch(model, loader, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda")
     assert np.isfinite(vl) and 0.0 <= vd <= 1.0 and 0.0 <= vi <= 1.0
 
 
@@ -382,7 +383,7 @@ def _oracle_amp_steps(O, batches, autocast: bool, init_scale: float = 65536.0):
 
 @pytest.mark.parametrize("scaler_kind", ["torch", "vk"])
 def test_amp_fp16_gradscaler_trajectory_vs_oracle(pair, scaler_kind):
-    """Three AMP steps through vk.train_one_epoch (fp16 autocast + GradScaler, the reference's own CUDA precision) against the
+    """Three AMP steps of the engine through the reference's epoch loop (oracle.train_one_epoch restates train.py:381-459; fp16 autocast + GradScaler, the reference's own CUDA precision) against the
     oracle: (i) fp32 (the reference's CPU branch) and (ii) the oracle under CPU fp16 autocast + GradScaler('cpu') — the
     reference's own mixed-precision arithmetic on another backend.
     Stated tolerances: per-step loss within 1e-2 relative of the fp32 oracle AND no further from it than 2x the autocast
@@ -402,7 +403,7 @@ def test_amp_fp16_gradscaler_trajectory_vs_oracle(pair, scaler_kind):
     scaler = (torch.amp.GradScaler if scaler_kind == "torch" else vk.GradScaler)("cuda", enabled=True)
     lg = []
     for xb, yb in batches:
-        lg.append(vk.train_one_epoch(model, [(xb, yb, ["a", "b"])], opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"),
+        lg.append(O.train_one_epoch(model, [(xb, yb, ["a", "b"])], opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"),
                                      "cuda", scaler))
     assert scaler.get_scale() == 65536.0 == sc16.get_scale()
     assert opt.step_count == 3
@@ -441,7 +442,7 @@ def test_amp_overflow_step_is_skipped_and_scale_halves(pair, scaler_kind):
     x, y = O.synthetic_batch(2, 64, seed=5)
     loader = [(x, y, ["a", "b"])]
     before = model.flat_params.clone()
-    loss = vk.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
+    loss = O.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
     torch.cuda.synchronize()
     assert np.isfinite(loss)                                   # the forward is fine; only the scaled gradients overflow
     assert torch.equal(before, model.flat_params)              # skipped
@@ -456,7 +457,7 @@ def test_amp_overflow_step_is_skipped_and_scale_halves(pair, scaler_kind):
     assert ts.get_scale() == scaler.get_scale() and int(ts._growth_tracker.item()) == int(scaler._growth_tracker.item())
     # recovery: the scale keeps halving until the gradients fit, then steps are taken and counted
     for _ in range(40):
-        vk.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
+        O.train_one_epoch(model, loader, opt, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda", scaler)
         if opt.step_count >= 3:
             break
     assert opt.step_count >= 3 and scaler.get_scale() < 2.0 ** 30

@@ -899,3 +899,62 @@ def test_adamw_amp_device_protocol_matches_torch():
     torch.cuda.synchronize()
     assert found.item() == 1.0
     assert lib.vk_amp_unscale_check(n - 1, gd.data_ptr(), None, found.data_ptr(), st()) < 0      # n % 4 != 0 is refused on the host
+
+
+# ------------------------------------------------------------------------------------------------ validation metrics (train.py:230-281)
+def test_seg_metrics_against_reference_golden():
+    """vk_seg_metrics against OUTPUTS OF THE REFERENCE'S OWN dice_coef / iou_coef (tests/golden/metrics_ref.json, produced by importing
+    /root/reference/train.py in the build container: tests/golden/make_golden.py) — a pinned known-answer, incl. the empty-target case."""
+    import json
+
+    from conftest import GOLDEN
+    for c in json.load(open(GOLDEN / "metrics_ref.json")):
+        g = torch.Generator().manual_seed(c["seed"])
+        prob = torch.rand(c["n"], 1, c["s"], c["s"], generator=g)
+        tgt = (torch.rand(c["n"], 1, c["s"], c["s"], generator=g) > c["thr"]).float()
+        if c["seed"] == 3:
+            tgt.zero_()
+            prob.mul_(0.4)
+        d, u = vk.dice_coef(D(prob), D(tgt)), vk.iou_coef(D(prob), D(tgt))
+        assert d == pytest.approx(c["dice"], abs=1.5e-7), c
+        assert u == pytest.approx(c["iou"], abs=1.5e-7), c
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 7, 5), (3, 1, 37, 53), (5, 1, 64, 64), (32, 1, 512, 512), (2, 1, 1024, 1024), (70, 1, 16, 16)])
+def test_seg_metrics_shapes_vs_oracle(shape):
+    """Ragged (non-16-byte) image sizes, a batch larger than the finalize workgroup, full-size maps, logits mode, other thresholds;
+    per-image values and the fp64 {I, P, T} sums are exact integers for 0/1 targets."""
+    from oracle import unet_oracle as O
+    g = torch.Generator().manual_seed(sum(shape))
+    logits = torch.randn(*shape, generator=g) * 3
+    prob = torch.sigmoid(logits)
+    tgt = (torch.rand(*shape, generator=g) > 0.7).float()
+    tgt[0].zero_()                                              # one empty target
+    if shape[0] > 1:
+        prob[1].fill_(0.1); logits[1].fill_(-2.0)               # one empty prediction
+    out = vk.seg_metrics_device(D(prob), D(tgt)).cpu()
+    assert out[0].item() == pytest.approx(O.dice_coef(prob, tgt), abs=2e-7)
+    assert out[1].item() == pytest.approx(O.iou_coef(prob, tgt), abs=2e-7)
+    pred = (prob > 0.5).float()
+    I, P, T = (pred * tgt).sum(dim=(1, 2, 3)), pred.sum(dim=(1, 2, 3)), tgt.sum(dim=(1, 2, 3))
+    assert torch.equal(out[2::2], (2 * I + 1e-7) / (P + T + 1e-7))          # per image: the reference's fp32 expressions, bit for bit
+    assert torch.equal(out[3::2], (I + 1e-7) / (P + T - I + 1e-7))
+    two = vk.seg_metrics_device(D(prob), D(tgt)).cpu()
+    assert torch.equal(out, two)                                            # reproducible
+    for thr in (0.25, 0.45):
+        d, u = vk.seg_metrics(D(prob), D(tgt), threshold=thr)
+        pr = (prob > thr).float()
+        i2, p2 = (pr * tgt).sum(dim=(1, 2, 3)), pr.sum(dim=(1, 2, 3))
+        assert d == pytest.approx(((2 * i2 + 1e-7) / (p2 + T + 1e-7)).mean().item(), abs=2e-7)
+        assert u == pytest.approx(((i2 + 1e-7) / (p2 + T - i2 + 1e-7)).mean().item(), abs=2e-7)
+    dl, ul = vk.seg_metrics(D(logits), D(tgt), from_logits=True)
+    # device expf vs torch's sigmoid can disagree only for |logit| within fp32 round-off of 0: none among N(0, 9) draws
+    assert dl == pytest.approx(out[0].item(), abs=1e-6) and ul == pytest.approx(out[1].item(), abs=1e-6)
+
+
+def test_seg_metrics_refuses_cpu_and_bad_arguments():
+    with pytest.raises(vk.VkError):
+        vk.dice_coef(torch.rand(1, 1, 8, 8), torch.zeros(1, 1, 8, 8))
+    lib = L_.lib()
+    assert lib.vk_seg_metrics(0, 64, 8, 8, 0, 0.5, 1e-7, 8, 24, 8, None) < 0
+    assert lib.vk_seg_metrics(2, 64, 8, 8, 0, 0.5, 1e-7, 8, 24, 8, None) < 0       # workspace too small for two images

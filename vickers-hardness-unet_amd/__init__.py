@@ -10,19 +10,19 @@ Import by string (the directory name carries hyphens)::
     optimizer = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
 
 Everything heavy runs in libvkunet.so (hand-written HIP); there is no CPU fallback."""
-from . import _lib, augment, geometry, losses, metrics, parallel, prepost  # noqa: F401
+from . import _lib, augment, geometry, losses, parallel, prepost, segmetrics, synthetic  # noqa: F401
 from .augment import AugmentSampler, DeviceDataset  # noqa: F401
 from .geometry import postprocess_minarearect_batch, postprocess_minarearect_multi  # noqa: F401
 from ._lib import VkError, build, lib  # noqa: F401
 from .losses import BCEDiceLoss, DiceLoss  # noqa: F401
-from .metrics import dice_coef, iou_coef  # noqa: F401
+from .segmetrics import dice_coef, iou_coef, seg_metrics, seg_metrics_device  # noqa: F401
 from .optim import FusedAdamW, GradScaler, adamw_for  # noqa: F401
 from .parallel import GradientReducer, all_reduce_scalars, broadcast_model, make_data_parallel  # noqa: F401
 from .prepost import Segmenter, predict_mask  # noqa: F401
-from .train import train_one_epoch, validate  # noqa: F401
+from .synthetic import seed_everything, synthetic_batch  # noqa: F401
 from .unet import Unet, build_model  # noqa: F401
 
 __all__ = ["Unet", "build_model", "DiceLoss", "BCEDiceLoss", "FusedAdamW", "GradScaler", "adamw_for", "GradientReducer",
-           "make_data_parallel", "broadcast_model", "all_reduce_scalars", "dice_coef", "iou_coef", "train_one_epoch", "validate",
-           "VkError", "build", "lib", "losses", "metrics", "parallel", "prepost", "Segmenter", "predict_mask", "geometry", "augment", "AugmentSampler", "DeviceDataset",
+           "make_data_parallel", "broadcast_model", "all_reduce_scalars", "dice_coef", "iou_coef", "seg_metrics", "seg_metrics_device", "synthetic_batch", "seed_everything",
+           "VkError", "build", "lib", "losses", "segmetrics", "synthetic", "parallel", "prepost", "Segmenter", "predict_mask", "geometry", "augment", "AugmentSampler", "DeviceDataset",
            "postprocess_minarearect_multi", "postprocess_minarearect_batch"]

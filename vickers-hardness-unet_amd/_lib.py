@@ -75,6 +75,7 @@ SIGNATURES = {
     "vk_last_error_string": (C.c_char_p, []),
     "vk_has_gfx950_code": (ci, []),
     "vk_probe_mfma_rate": (ci, [ci, ci, vp, P(C.c_double), vp]),
+    "vk_debug_hold_cus": (ci, [ci, ci, ci, ci, vp, sz, vp, vp]),
     "vk_debug_set_stamp_buffer": (ci, [vp]),
     "vk_prof_enable": (ci, [ci]),
     "vk_prof_collect": (ci, [C.c_char_p, sz]),
@@ -112,6 +113,8 @@ SIGNATURES = {
     "vk_head_fwd": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp]),
     "vk_head_bwd": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp, vp, vp, sz, vp]),
     "vk_bce_dice_loss": (ci, [sz, vp, vp, vp, vp, vp, cf, cf, cf, vp]),
+    "vk_seg_metrics_workspace_bytes": (C.c_size_t, [ci]),
+    "vk_seg_metrics": (ci, [ci, sz, vp, vp, ci, cf, cf, vp, sz, vp, vp]),
     "vk_adamw_step": (ci, [sz, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, cf, vp, vp, ci, vp]),
     "vk_amp_check_inf": (ci, [sz, vp, vp, vp]),
     "vk_amp_unscale_check": (ci, [sz, vp, vp, vp, vp]),

@@ -138,6 +138,30 @@ __global__ __launch_bounds__(256) void k_mfma_rate(int iters, float* sink) {
   if (t == 123.456f) sink[0] = t;                           // keeps the loop alive
 }
 
+// vk_debug_hold_cus: spin until a wall-clock deadline (100 MHz s_memrealtime), optionally streaming loads meanwhile
+__global__ void k_hold_cus(unsigned long long ticks, const u32x4_t* __restrict__ traffic, size_t traffic_vecs, float* sink) {
+  extern __shared__ char hold_lds[];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  uint32_t acc = 0;
+  size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) & (traffic_vecs ? traffic_vecs - 1 : 0);
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    if (traffic) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4_t v = __builtin_nontemporal_load(traffic + i);
+        acc ^= v[0] ^ v[3];
+        i = (i + (size_t)gridDim.x * blockDim.x) & (traffic_vecs - 1);
+      }
+    } else {
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  if (acc == 0x9E3779B9u && threadIdx.x == 0) {       // keeps the loads alive; LDS is declared, never needed
+    hold_lds[0] = 1;
+    sink[0] = (float)hold_lds[0];
+  }
+}
+
 // ---------------------------------------------------------------- weight packing kernels
 struct PackEntry {
   int64_t src, dst;     // element offsets: flat params / dgrad arena
@@ -674,6 +698,20 @@ extern "C" int vk_probe_mfma_rate(int iters, int waves_per_simd, float* sink, do
   const int blocks = cus * waves_per_simd;                  // 256 threads = one wave per SIMD of a CU
   if (flops_out) *flops_out = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16.0 * 16.0 * 32.0;
   hipLaunchKernelGGL(vk::k_mfma_rate, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_debug_hold_cus(int workgroups, int threads, int lds_bytes, int microseconds, const void* traffic, size_t traffic_bytes,
+                                 float* sink, void* stream) {
+  VK_CHECK_ARG(workgroups >= 1 && workgroups <= 4096 && threads >= 64 && threads <= 1024 && threads % 64 == 0, "vk_debug_hold_cus: bad grid");
+  VK_CHECK_ARG(lds_bytes >= 0 && lds_bytes <= 163840 && microseconds >= 1 && microseconds <= 2000000 && sink, "vk_debug_hold_cus: bad argument");
+  VK_CHECK_ARG(!traffic || (traffic_bytes >= 65536 && (traffic_bytes & (traffic_bytes - 1)) == 0 && ((uintptr_t)traffic & 15) == 0),
+               "vk_debug_hold_cus: traffic buffer must be a 16-byte aligned power of two >= 64 KiB");
+  if (lds_bytes > 65536)
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)vk::k_hold_cus, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+  hipLaunchKernelGGL(vk::k_hold_cus, dim3((unsigned)workgroups), dim3((unsigned)threads), (size_t)lds_bytes, (hipStream_t)stream,
+                     (unsigned long long)microseconds * 100ull, (const vk::u32x4_t*)traffic, traffic ? traffic_bytes / 16 : (size_t)0, sink);
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }
