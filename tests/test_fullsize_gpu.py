@@ -5,7 +5,9 @@ configs[4] geometry (fp16 + loss scale 2^16, bs 8, 1024x1024, one step) run on t
 Compared, with the tolerance in each assert:
   * step-1 loss and both of its components (BCE, Dice)           rel <= 1e-2
   * the three-step loss trajectory                               rel <= 2e-2 per step, and it decreases like the oracle's
-  * BatchNorm running statistics of the first and the last BN    <= 2e-3 relative to the statistic's scale (first), see test (last)
+  * BatchNorm running statistics of the first and the last BN    fp16: <= 2e-3 of the statistic's scale; bf16: <= 1e-2 / 3e-2
+    (rounding a filter to 8 mantissa bits moves a channel mean of N(0,1) inputs by ~2^-9 of the filter norm: the oracle under CPU
+    bf16 autocast, printed beside it, is off by the same amount)
   * gradient direction of named parameters against the fp32 oracle, with the oracle under CPU bf16 autocast — the reference's
     own mixed-precision arithmetic on another backend — as the yardstick (cosine no worse than the yardstick's - 0.02)
 The oracle steps cost ~10 s each on the 16 host threads of a GPU box; nothing here reads /root/reference."""
@@ -40,6 +42,7 @@ def _oracle_steps(O, x, y, steps, autocast_dtype=None):
     opt = torch.optim.AdamW(ref.parameters(), lr=5e-5, weight_decay=1e-4)
     bce, dice = torch.nn.BCEWithLogitsLoss(), O.DiceLoss()
     rec, grads = [], None
+    ref.stats_after_step1 = None
     for s in range(steps):
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cpu", dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
@@ -50,6 +53,7 @@ def _oracle_steps(O, x, y, steps, autocast_dtype=None):
         if s == 0:
             named = dict(ref.named_parameters())
             grads = {k: named[k].grad.detach().clone() for k in NAMED}
+            ref.stats_after_step1 = {k: v.clone() for k, v in ref.state_dict().items() if "running_" in k}
         opt.step()
         rec.append((loss.item(), lb.item(), ld.item()))
     return rec, grads, ref
@@ -75,7 +79,10 @@ def _engine_steps(O, x, y, steps, dtype, loss_scale=1.0):
     return rec, grads, model
 
 
-def _compare(tag, eng, ora, yard, g_e, g_o, g_y, model, ref, steps):
+BN_KEYS = ("encoder.bn1.running_mean", "encoder.bn1.running_var", "decoder.blocks.4.conv2.1.running_mean", "decoder.blocks.4.conv2.1.running_var")
+
+
+def _compare(tag, eng, ora, yard, g_e, g_o, g_y, model, ref, steps, bn_bars=(2e-3, 2e-3, 2e-3, 2e-3), yard_stats=None):
     print(f"[{tag}] losses (total, bce, dice) engine {eng} | fp32 oracle {ora}" + (f" | autocast oracle {yard}" if yard else ""))
     # step 1: total and both components
     for j, nm in enumerate(("total", "bce", "dice")):
@@ -88,12 +95,14 @@ def _compare(tag, eng, ora, yard, g_e, g_o, g_y, model, ref, steps):
         assert (eng[0][0] - eng[-1][0]) == pytest.approx(ora[0][0] - ora[-1][0], rel=0.25), (eng, ora)
     # BatchNorm running statistics after `steps` momentum-0.1 updates
     sd_e, sd_o = model.state_dict(), ref.state_dict()
-    for k, bar in (("encoder.bn1.running_mean", 2e-3), ("encoder.bn1.running_var", 2e-3),
-                   ("decoder.blocks.4.conv2.1.running_mean", 2e-2), ("decoder.blocks.4.conv2.1.running_var", 2e-2)):
+    for k, bar in zip(BN_KEYS, bn_bars):
         a, b = sd_e[k].cpu(), sd_o[k]
         err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
-        print(f"[{tag}] {k}: max|diff| / max|oracle| = {err:.2e}")
-        # the LAST BatchNorm sits behind 45 layers of 16-bit arithmetic: its bar is 2e-2 (the first one sees only the stem: 2e-3)
+        note = ""
+        if yard_stats is not None:      # the mixed-precision oracle after ITS one step against the fp32 oracle after one step
+            b1 = ref.stats_after_step1[k]
+            note = f" (autocast oracle after one step: {(yard_stats[k] - b1).abs().max().item() / (b1.abs().max().item() + 1e-12):.2e})"
+        print(f"[{tag}] {k}: max|diff| / max|oracle| = {err:.2e}{note}")
         assert err <= bar, (k, err)
     assert int(sd_e["encoder.bn1.num_batches_tracked"]) == steps == int(sd_o["encoder.bn1.num_batches_tracked"])
     # gradient direction, step 1
@@ -122,11 +131,12 @@ def test_config3_bf16_bs32_512_three_steps_vs_oracle():
     ora, g_o, ref = _oracle_steps(O, x, y, 3)
     t1 = time.perf_counter()
     yard, g_y, ref_y = _oracle_steps(O, x, y, 1, autocast_dtype=torch.bfloat16)
+    yard_stats = ref_y.stats_after_step1
     del ref_y
     t2 = time.perf_counter()
     eng, g_e, model = _engine_steps(O, x, y, 3, torch.bfloat16)
     print(f"[configs[2]] oracle fp32 3 steps {t1 - t0:.1f} s, autocast oracle 1 step {t2 - t1:.1f} s")
-    _compare("configs[2] bf16 bs32 512", eng, ora, yard, g_e, g_o, g_y, model, ref, 3)
+    _compare("configs[2] bf16 bs32 512", eng, ora, yard, g_e, g_o, g_y, model, ref, 3, bn_bars=(1e-2, 1e-2, 3e-2, 3e-2), yard_stats=yard_stats)
 
 
 def test_config5_fp16_bs8_1024_one_step_vs_oracle():

@@ -43,6 +43,11 @@ def main():
             parts.append(f"valu_mfma_coexec {m['SQ_VALU_MFMA_COEXEC_CYCLES']:11.0f}")
         if m.get("SQ_LDS_IDX_ACTIVE"):
             parts.append(f"lds_active {m['SQ_LDS_IDX_ACTIVE']:11.0f}  lds_conflict {100 * m.get('SQ_LDS_BANK_CONFLICT', 0) / m['SQ_LDS_IDX_ACTIVE']:5.1f}%")
+        shown = {"SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE",
+                 "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"}
+        for c in sorted(m):
+            if c not in shown:
+                parts.append(f"{c[3:] if c.startswith('SQ_') else c} {m[c]:.0f}")
         print("  ".join(parts))
 
 
