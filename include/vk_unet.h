@@ -21,6 +21,7 @@
  *   vk_letterbox_postprocess_mask ............. sigmoid, threshold, un-letterbox  infer_pth_gui.py:26-29, 50-53
  *   vk_letterbox_postprocess_prob ............. sigmoid, un-letterbox, clip       ui_infer_quadrilateral.py:219-231, 705-711
  *   vk_geom_minarearect ....................... postprocess_minarearect_multi      ui_infer_rectangle.py:291-381
+ *   vk_geom_quadrilateral ..................... postprocess_minarearect_multi + robust_quadrilateral_from_contour  ui_infer_quadrilateral.py:262-530
  *   vk_letterbox_u8 / _mask_u8 / vk_augment_batch  VickersDataset.__getitem__ + albumentations pipeline  train.py:67-113, 173-200
  *
  * Conventions
@@ -227,6 +228,30 @@ int64_t vk_geom_workspace_bytes(const vk_geom_desc* d, int batch);      /* < 0: 
  * label order (the host sorts by area like ui_infer_rectangle.py:379).  counts: int32 [batch] = kept components per map. */
 int vk_geom_minarearect(const vk_geom_desc* d, int batch, const float* prob, uint8_t* clean, vk_geom_det* dets, int* counts,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* The newer GUI's post-processing (ui_infer_quadrilateral.py:423-530 `postprocess_minarearect_multi` with its helpers :262-420):
+ * steps 1-3 as above (bin_thresh 0.45 there), then per kept component: dilate by the (2 fit_outset_px + 1)^2 MORPH_ELLIPSE element
+ * (fit only: `clean` and `area` are untouched), external border (cv2.findContours RETR_EXTERNAL / CHAIN_APPROX_SIMPLE), convex hull,
+ * cv2.approxPolyDP epsilon bisection to exactly four vertices on both polygons, the sub-sampling and extreme-point fall-backs,
+ * (quality, area) ranking of the candidates, clockwise ordering, int32 corners and the two diagonals. */
+typedef struct {
+  int label;            /* as vk_geom_det */
+  int area;             /* pixels of the component (before the fit dilation) */
+  int box[8];           /* x0,y0 .. x3,y3: the quadrilateral, ordered by _order_quad_cw (:266-277), starting at its top-most corner */
+  float cx, cy;         /* mean of the four corners */
+  int valid;            /* 0: no quadrilateral was found (the reference drops such a component from its list) */
+  int branch;           /* which step produced the candidates: 1 epsilon bisection, 2 four consecutive vertices of the 1 % polygon, 3 extreme points */
+  int n_candidates;
+  int contour_n;        /* points of the CHAIN_APPROX_SIMPLE border */
+  int hull_n;           /* convex-hull vertices of the dilated component */
+  int flags;            /* bit 0: border longer than the 16,384-point buffer (hull candidate only); bit 1: hull > 4,096 vertices; bit 2: trace aborted */
+  double quality;       /* _quad_quality of the chosen candidate */
+  double d1, d2, d_mean;
+} vk_geom_quad;
+
+/* as vk_geom_minarearect (same workspace size: vk_geom_workspace_bytes); fit_outset_px 0..3 (reference default 2) */
+int vk_geom_quadrilateral(const vk_geom_desc* d, int fit_outset_px, int batch, const float* prob, uint8_t* clean, vk_geom_quad* dets,
+                          int* counts, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training-time augmentation on the device: VickersDataset.__getitem__ (train.py:173-200) with the

@@ -17,6 +17,11 @@ Fixtures written next to this file:
                            3-step AdamW loss trajectory at N=2, S=64 under seed 42 / data seed 1234
                            (G2-G4).  Detects drift of the oracle itself.
 
+* ``real_masks.npz``     — eight of the reference's own hand-labelled masks (data/masks/*.png: data files, mode L),
+                           binarised `> 0` as train.py:163-170 reads them and bit-packed: real indentation shapes
+                           (1280x1024 and 3072x2048 micrographs, 0.1 % to 27 % foreground) as inputs of both geometry
+                           post-processing paths.  Inputs only: the reference holds no detection list to compare with.
+
 The reference's source never travels: only these data files do.
 """
 import json
@@ -97,7 +102,33 @@ def manifest_and_small():
         **{"grad::" + k: v for k, v in grads.items()})
 
 
+REAL_MASKS = ("1.png", "4 (2).png", "image001 (4).png", "image003 (15).png", "image005 (3).png", "image011_(7)_dual.png")
+
+
+def real_masks():
+    """Bit-packed copies of a few label masks of the reference's dataset (largest / smallest foreground, both micrograph sizes)."""
+    from PIL import Image
+
+    files = sorted((REF / "data" / "masks").glob("*.png"))
+    by_name = {f.name: f for f in files}
+    pick = [by_name[n] for n in REAL_MASKS if n in by_name]
+    big = [f for f in files if Image.open(f).size == (3072, 2048)]
+    stats = sorted(((float((np.array(Image.open(f)) > 0).mean()), f) for f in big), key=lambda t: t[0])
+    pick += [stats[0][1], stats[len(stats) // 2][1], stats[-1][1]]          # 3072x2048: least / median / most foreground
+    out = {}
+    names = []
+    for i, f in enumerate(dict.fromkeys(pick)):
+        m = np.array(Image.open(f).convert("L")) > 0
+        out[f"bits_{i}"] = np.packbits(m, axis=1)
+        out[f"shape_{i}"] = np.array(m.shape, dtype=np.int32)
+        names.append(f.name)
+    out["names"] = np.array(names)
+    np.savez_compressed(HERE / "real_masks.npz", **out)
+    print("real masks:", names, {k: v.shape for k, v in out.items() if k.startswith("shape")})
+
+
 if __name__ == "__main__":
+    real_masks()
     lr_history()
     metrics_ref()
     manifest_and_small()

@@ -72,6 +72,26 @@ def main():
         mb = B * h * w * 5 / 1e6
         print(f"  B={B:3d} {h}x{w}: {us:9.1f} us = {us / B:8.1f} us/map ({mb / us * 1e3:7.1f} GB/s of 5 algorithmic B/px); "
               f"host mirror incl. allocation + read-back {host_ms:7.2f} ms; components kept: {[len(d) for d in det][:4]}")
+    print("== 4-vertex fit (ui_infer_quadrilateral.py:262-530): steps 1-3 + one wave per component (dilation, border following, hull, "
+          "approxPolyDP bisection, ranking)")
+    for B, h, w in ((1, 512, 512), (32, 512, 512), (1, 2048, 3072), (8, 2048, 3072)):
+        prob = torch.from_numpy(prob_maps(min(B, 4), h, w)).to(dev)
+        prob = prob.repeat((B + prob.shape[0] - 1) // prob.shape[0], 1, 1)[:B].contiguous()
+        desc = L.vk_geom_desc(h, w, 0.45, 3, 1, 1, max(200, int(0.0008 * h * w)), 64)
+        nbytes = lib.vk_geom_workspace_bytes(C.byref(desc), B)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        clean = torch.empty(B, h, w, dtype=torch.uint8, device=dev)
+        dets = torch.zeros(B * 64 * C.sizeof(L.vk_geom_quad), dtype=torch.uint8, device=dev)
+        counts = torch.zeros(B, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+
+        def runq():
+            L.check(lib.vk_geom_quadrilateral(C.byref(desc), 2, B, prob.data_ptr(), clean.data_ptr(), dets.data_ptr(), counts.data_ptr(), ws.data_ptr(), nbytes, st))
+        us = timed(runq)
+        _, det = vk.postprocess_quadrilateral_batch(prob)
+        pts = [d["contour_points"] for ds_ in det for d in ds_]
+        print(f"  B={B:3d} {h}x{w}: {us:9.1f} us = {us / B:8.1f} us/map; components {sum(len(d) for d in det)}, border points per component "
+              f"{min(pts) if pts else 0}-{max(pts) if pts else 0}, branches {sorted({d['branch'] for ds_ in det for d in ds_})}")
     print("== augmentation (train.py:67-113), one fused launch per batch")
     rng = np.random.default_rng(1)
     imgs = [rng.integers(0, 256, (1024, 1280, 3), dtype=np.uint8) for _ in range(4)]

@@ -12,7 +12,8 @@ Import by string (the directory name carries hyphens)::
 Everything heavy runs in libvkunet.so (hand-written HIP); there is no CPU fallback."""
 from . import _lib, augment, geometry, losses, parallel, prepost, segmetrics, synthetic  # noqa: F401
 from .augment import AugmentSampler, DeviceDataset  # noqa: F401
-from .geometry import postprocess_minarearect_batch, postprocess_minarearect_multi  # noqa: F401
+from .geometry import (postprocess_minarearect_batch, postprocess_minarearect_multi, postprocess_quadrilateral_batch,  # noqa: F401
+                       postprocess_quadrilateral_multi)
 from ._lib import VkError, build, lib  # noqa: F401
 from .losses import BCEDiceLoss, DiceLoss  # noqa: F401
 from .segmetrics import dice_coef, iou_coef, seg_metrics, seg_metrics_device  # noqa: F401
@@ -25,4 +26,4 @@ from .unet import Unet, build_model  # noqa: F401
 __all__ = ["Unet", "build_model", "DiceLoss", "BCEDiceLoss", "FusedAdamW", "GradScaler", "adamw_for", "GradientReducer",
            "make_data_parallel", "broadcast_model", "all_reduce_scalars", "dice_coef", "iou_coef", "seg_metrics", "seg_metrics_device", "synthetic_batch", "seed_everything",
            "VkError", "build", "lib", "losses", "segmetrics", "synthetic", "parallel", "prepost", "Segmenter", "predict_mask", "geometry", "augment", "AugmentSampler", "DeviceDataset",
-           "postprocess_minarearect_multi", "postprocess_minarearect_batch"]
+           "postprocess_minarearect_multi", "postprocess_minarearect_batch", "postprocess_quadrilateral_multi", "postprocess_quadrilateral_batch"]

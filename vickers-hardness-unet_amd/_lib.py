@@ -51,6 +51,12 @@ class vk_geom_det(C.Structure):
                 ("reserved", C.c_int), ("d1", C.c_double), ("d2", C.c_double), ("d_mean", C.c_double)]
 
 
+class vk_geom_quad(C.Structure):
+    _fields_ = [("label", C.c_int), ("area", C.c_int), ("box", C.c_int * 8), ("cx", C.c_float), ("cy", C.c_float),
+                ("valid", C.c_int), ("branch", C.c_int), ("n_candidates", C.c_int), ("contour_n", C.c_int), ("hull_n", C.c_int),
+                ("flags", C.c_int), ("quality", C.c_double), ("d1", C.c_double), ("d2", C.c_double), ("d_mean", C.c_double)]
+
+
 class vk_aug_params(C.Structure):
     _fields_ = [("d4", C.c_int), ("rotate", C.c_int), ("cos_a", C.c_float), ("sin_a", C.c_float), ("photo", C.c_int),
                 ("alpha", C.c_float), ("beta", C.c_float), ("blur_ksize", C.c_int), ("noise_scale", C.c_float),
@@ -95,6 +101,7 @@ SIGNATURES = {
     "vk_letterbox_postprocess_prob": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
     "vk_geom_workspace_bytes": (i64, [P(vk_geom_desc), ci]),
     "vk_geom_minarearect": (ci, [P(vk_geom_desc), ci, vp, vp, vp, vp, vp, sz, vp]),
+    "vk_geom_quadrilateral": (ci, [P(vk_geom_desc), ci, ci, vp, vp, vp, vp, vp, sz, vp]),
     "vk_letterbox_u8": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
     "vk_letterbox_mask_u8": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
     "vk_augment_workspace_bytes": (C.c_size_t, [ci, ci]),

@@ -464,6 +464,517 @@ __global__ __launch_bounds__(256) void k_geom_rect(int h, int max_comp, const in
   out[(size_t)b * max_comp + slot] = o;
 }
 
+
+// ---------------------------------------------------------------------------------------------- the 4-vertex fit
+// ui_infer_quadrilateral.py:262-530 (the newer GUI): per kept component, dilate by the fit_outset_px ellipse, trace the external
+// border (cv2.findContours RETR_EXTERNAL / CHAIN_APPROX_SIMPLE: Suzuki-Abe border following), take the convex hull, run
+// cv2.approxPolyDP with an epsilon bisection on both polygons until exactly four vertices come out, fall back to four consecutive
+// vertices of a 1 % approximation and then to the hull's extreme points, pick the candidate with the best (quality, area) key,
+// order it clockwise and measure its diagonals.  oracle/quad_oracle.py restates the same steps in numpy; both sides use the same
+// types in the same operation order (integer-valued coordinates: every Douglas-Peucker distance is exact in float64).
+//
+// One WAVE per component (the control flow of border following and of the Douglas-Peucker stack is sequential; the 64 lanes share
+// the loads of a tracing step and the arg-max scans over a polygon).  Everything that decides control flow is wave-uniform.
+struct GeomQuadOut {      // mirrors vk_geom_quad (include/vk_unet.h)
+  int label, area;
+  int box[8];
+  float cx, cy;
+  int valid, branch, n_candidates, contour_n, hull_n, flags;
+  double quality, d1, d2, d_mean;
+};
+static_assert(sizeof(GeomQuadOut) == sizeof(vk_geom_quad), "vk_geom_quad layout");
+
+constexpr int GQ_NC = 16384;         // capacity of the contour and of the approximation buffers (points)
+constexpr int GQ_NH = 4096;          // capacity of the hull
+constexpr int GQ_LDS = (2 * GQ_NC + GQ_NH) * 4;
+constexpr int GQ_MAX_STEPS = 1 << 21;
+
+// chain-code steps: 0..7 = E, NE, N, NW, W, SW, S, SE with y growing downwards (OpenCV's CV_INIT_3X3_DELTAS order)
+__device__ __forceinline__ int gq_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }
+__device__ __forceinline__ int gq_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }
+__device__ __forceinline__ uint32_t gq_pack(int x, int y) { return (uint32_t)x | ((uint32_t)y << 16); }
+__device__ __forceinline__ int gq_x(uint32_t p) { return (int)(p & 0xFFFFu); }
+__device__ __forceinline__ int gq_y(uint32_t p) { return (int)(p >> 16); }
+
+// wave arg-max of (value, smallest key among equal values); every lane returns the winner
+__device__ __forceinline__ void gq_wave_argmax(double& v, int& key) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(v, o, 64);
+    const int ok = __shfl_xor(key, o, 64);
+    if (ov > v || (ov == v && ok < key)) { v = ov; key = ok; }
+  }
+}
+
+// cv2.arcLength(poly, closed): float32 segment lengths summed in float64.  Lengths are >= 1 with 24-bit mantissas and the sum stays
+// below 2^20, so every partial sum is exact in float64 and the order of the additions cannot matter.
+__device__ double gq_arc_length(const uint32_t* src, int count) {
+#pragma clang fp contract(off)
+  if (count <= 1) return 0.0;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += 64) {
+    const uint32_t a = src[i == 0 ? count - 1 : i - 1], b = src[i];
+    const float dx = (float)(gq_x(b) - gq_x(a)), dy = (float)(gq_y(b) - gq_y(a));
+    s += (double)sqrtf(dx * dx + dy * dy);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
+
+// cv2.approxPolyDP(src, epsilon, closed = true) -> dst[0 .. return value).  buf has GQ_NC words: output points grow from the bottom,
+// the slice stack (start | end << 16) from the top; they cannot meet (every stacked slice still owes at least one output point).
+__device__ int gq_approx_closed(const uint32_t* src, int count, double epsilon, uint32_t* buf) {
+#pragma clang fp contract(off)
+  if (count == 0) return 0;
+  const double eps = epsilon * epsilon;
+  int n = 0, top = GQ_NC;
+  // 1. three farthest-point sweeps
+  int pos = 0, right_start = 0;
+  bool le_eps = false;
+  for (int it = 0; it < 3; ++it) {
+    pos = (pos + right_start) % count;
+    const uint32_t sp = src[pos];
+    const double sx = (double)gq_x(sp), sy = (double)gq_y(sp);
+    double best = 0.0;
+    int bj = 0x7FFFFFFF;
+    for (int j = 1 + (int)threadIdx.x; j < count; j += 64) {
+      int q = pos + j; if (q >= count) q -= count;
+      const uint32_t pt = src[q];
+      const double dx = (double)gq_x(pt) - sx, dy = (double)gq_y(pt) - sy;
+      const double d = dx * dx + dy * dy;
+      if (d > best) { best = d; bj = j; }
+    }
+    gq_wave_argmax(best, bj);
+    if (best > 0.0) right_start = bj;       // "dist > max_dist" never fires on all-zero distances: right_start keeps its value
+    le_eps = best <= eps;
+  }
+  if (!le_eps) {
+    const int a = pos % count, b = (right_start + a) % count;
+    buf[--top] = (uint32_t)b | ((uint32_t)a << 16);      // right slice
+    buf[--top] = (uint32_t)a | ((uint32_t)b << 16);
+  } else {
+    buf[n++] = src[pos];
+  }
+  // 2. split slices at their farthest point
+  while (top < GQ_NC) {
+    const uint32_t sl = buf[top++];
+    const int s0 = (int)(sl & 0xFFFFu), s1 = (int)(sl >> 16);
+    const uint32_t sp = src[s0], ep = src[s1];
+    int first = s0 + 1; if (first >= count) first = 0;
+    bool le = true;
+    int split = 0;
+    if (first != s1) {
+      const double sx = (double)gq_x(sp), sy = (double)gq_y(sp);
+      const double dx = (double)gq_x(ep) - sx, dy = (double)gq_y(ep) - sy;
+      int len = s1 - first; if (len < 0) len += count;          // points strictly between the slice ends
+      double best = 0.0;
+      int bk = 0x7FFFFFFF;
+      for (int k = threadIdx.x; k < len; k += 64) {
+        int q = first + k; if (q >= count) q -= count;
+        const uint32_t pt = src[q];
+        const double d = fabs(((double)gq_y(pt) - sy) * dx - ((double)gq_x(pt) - sx) * dy);
+        if (d > best) { best = d; bk = k; }
+      }
+      gq_wave_argmax(best, bk);
+      if (best > 0.0) { split = first + bk; if (split >= count) split -= count; }
+      le = best * best <= eps * (dx * dx + dy * dy);
+    }
+    if (le) {
+      buf[n++] = sp;
+    } else {
+      buf[--top] = (uint32_t)split | ((uint32_t)s1 << 16);
+      buf[--top] = (uint32_t)s0 | ((uint32_t)split << 16);
+    }
+  }
+  // 3. in-place clean-up of nearly straight runs (sequential; reads near the wrap-around see rewritten entries, as in OpenCV)
+  const int cnt = n;
+  int new_count = n;
+  if (cnt == 0) return 0;
+  int rp = cnt - 1;
+  uint32_t start_pt = buf[rp]; rp = rp + 1 >= cnt ? 0 : rp + 1;
+  int wpos = rp;
+  uint32_t pt = buf[rp]; rp = rp + 1 >= cnt ? 0 : rp + 1;
+  for (int i = 0; i < cnt && new_count > 2; ++i) {
+    const uint32_t end_pt = buf[rp]; rp = rp + 1 >= cnt ? 0 : rp + 1;
+    const double dx = (double)(gq_x(end_pt) - gq_x(start_pt)), dy = (double)(gq_y(end_pt) - gq_y(start_pt));
+    const double px = (double)(gq_x(pt) - gq_x(start_pt)), py = (double)(gq_y(pt) - gq_y(start_pt));
+    const double dist = fabs(px * dy - py * dx);
+    const double inner = px * (double)(gq_x(end_pt) - gq_x(pt)) + py * (double)(gq_y(end_pt) - gq_y(pt));
+    if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0.0 && dy != 0.0 && inner >= 0.0) {
+      --new_count;
+      buf[wpos] = start_pt = end_pt;
+      wpos = wpos + 1 >= cnt ? 0 : wpos + 1;
+      pt = buf[rp]; rp = rp + 1 >= cnt ? 0 : rp + 1;
+      ++i;
+      continue;
+    }
+    buf[wpos] = start_pt = pt;
+    wpos = wpos + 1 >= cnt ? 0 : wpos + 1;
+    pt = end_pt;
+  }
+  return new_count;
+}
+
+struct GqQuad { float x[4], y[4]; };
+
+// _order_quad_cw (:266-277)
+__device__ GqQuad gq_order_cw(const GqQuad& q) {
+#pragma clang fp contract(off)
+  const float cx = (((q.x[0] + q.x[1]) + q.x[2]) + q.x[3]) / 4.f, cy = (((q.y[0] + q.y[1]) + q.y[2]) + q.y[3]) / 4.f;
+  float ang[4];
+  int idx[4] = {0, 1, 2, 3};
+  for (int i = 0; i < 4; ++i) ang[i] = atan2f(q.y[i] - cy, q.x[i] - cx);
+  for (int i = 1; i < 4; ++i)                    // stable ascending insertion sort
+    for (int j = i; j > 0 && ang[idx[j]] < ang[idx[j - 1]]; --j) { const int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t; }
+  GqQuad r;
+  for (int i = 0; i < 4; ++i) { r.x[i] = q.x[idx[3 - i]]; r.y[i] = q.y[idx[3 - i]]; }
+  int k = 0;
+  for (int i = 1; i < 4; ++i)
+    if (r.y[i] < r.y[k] || (r.y[i] == r.y[k] && r.x[i] < r.x[k])) k = i;
+  GqQuad o;
+  for (int i = 0; i < 4; ++i) { o.x[i] = r.x[(i + k) & 3]; o.y[i] = r.y[(i + k) & 3]; }
+  return o;
+}
+
+// _poly_area (:298-301): float32 shoelace, the two dot products summed left to right
+__device__ double gq_area(const GqQuad& q) {
+#pragma clang fp contract(off)
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    s1 = s1 + q.x[i] * q.y[(i + 1) & 3];
+    s2 = s2 + q.y[i] * q.x[(i + 1) & 3];
+  }
+  return fabs((double)(s1 - s2)) * 0.5;
+}
+
+// _is_convex_quad (:280-295)
+__device__ bool gq_convex(const GqQuad& q) {
+#pragma clang fp contract(off)
+  bool all_ge = true, all_le = true;
+  for (int i = 0; i < 4; ++i) {
+    const int b = (i + 1) & 3, c = (i + 2) & 3;
+    const float v1x = q.x[b] - q.x[i], v1y = q.y[b] - q.y[i], v2x = q.x[c] - q.x[b], v2y = q.y[c] - q.y[b];
+    const float cr = v1x * v2y - v1y * v2x;
+    all_ge = all_ge && cr >= 0.f;
+    all_le = all_le && cr <= 0.f;
+  }
+  return all_ge || all_le;
+}
+
+// _quad_quality (:304-330)
+__device__ double gq_quality(const GqQuad& q) {
+#pragma clang fp contract(off)
+  float d[4];
+  for (int i = 0; i < 4; ++i) {
+    const float vx = q.x[i] - q.x[(i + 1) & 3], vy = q.y[i] - q.y[(i + 1) & 3];
+    d[i] = sqrtf(vx * vx + vy * vy);
+  }
+  const float peri = (((d[0] + d[1]) + d[2]) + d[3]) + 1e-6f;
+  double pen = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    const int a = (i + 3) & 3, c = (i + 1) & 3;
+    const float v1x = q.x[a] - q.x[i], v1y = q.y[a] - q.y[i], v2x = q.x[c] - q.x[i], v2y = q.y[c] - q.y[i];
+    const float dot = v1x * v2x + v1y * v2y;
+    const float n1 = sqrtf(v1x * v1x + v1y * v1y), n2 = sqrtf(v2x * v2x + v2y * v2y);
+    float cs = dot / (n1 * n2 + 1e-6f);
+    cs = fminf(fmaxf(cs, -1.f), 1.f);
+    const double ang = acos((double)cs) * (180.0 / 3.14159265358979323846);
+    pen += (ang >= 15.0 && ang <= 165.0) ? 0.0 : 1.0;
+  }
+  const double ang_pen = pen / 4.0;
+  const float dmax = fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3])), dmin = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+  const float ratio = (dmax + 1e-6f) / (dmin + 1e-6f);
+  const float dev = fabsf(ratio - 1.f);
+  const float ed_pen = dev < 1.f ? dev : 1.f;             // min(1.0, |ratio - 1|)
+  const float shape = 1.f - 0.5f * ed_pen;
+  const float size = peri / (peri + 1000.f);
+  return (1.0 - 0.5 * ang_pen) * (double)shape * (double)size;
+}
+
+struct GqBest {
+  bool have;
+  GqQuad q;
+  double quality, area;
+  int ncand;
+};
+__device__ __forceinline__ void gq_offer(GqBest& b, const GqQuad& cand) {     // stable sort, reverse=True, [0]: the first maximal key
+  const double ql = gq_quality(cand), ar = gq_area(cand);
+  ++b.ncand;
+  if (!b.have || ql > b.quality || (ql == b.quality && ar > b.area)) { b.have = true; b.q = cand; b.quality = ql; b.area = ar; }
+}
+__device__ __forceinline__ GqQuad gq_from(const uint32_t* p, int i0, int i1, int i2, int i3) {
+  GqQuad q;
+  const int ix[4] = {i0, i1, i2, i3};
+  for (int i = 0; i < 4; ++i) { q.x[i] = (float)gq_x(p[ix[i]]); q.y[i] = (float)gq_y(p[ix[i]]); }
+  return q;
+}
+
+// _try_poly_dp (:352-378): epsilon bisection on one polygon; true + the ordered quadrilateral when one was found
+__device__ bool gq_try_poly(const uint32_t* src, int count, uint32_t* buf, GqQuad* out) {
+#pragma clang fp contract(off)
+  const double peri = gq_arc_length(src, count);
+  double lo = 0.001 * peri, hi = 0.08 * peri;
+  for (int it = 0; it < 25; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    const int n = gq_approx_closed(src, count, mid, buf);
+    if (n == 4) {
+      const GqQuad cand = gq_order_cw(gq_from(buf, 0, 1, 2, 3));
+      if (gq_area(cand) > 10.0 && gq_convex(cand)) { *out = cand; return true; }
+      lo = mid;
+    } else if (n > 4) {
+      lo = mid;
+    } else {
+      hi = mid;
+    }
+    if (fabs(hi - lo) < 1e-6) break;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(64) void k_geom_quad(int h, int w, int max_comp, const int* __restrict__ tot, const GeomComp* __restrict__ comps,
+                                                  const int* __restrict__ rows, const int* __restrict__ Lb, const GeomSE se,
+                                                  GeomQuadOut* __restrict__ out, int* __restrict__ counts) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.y, slot = blockIdx.x;
+  const int nkept = tot[b * 2 + 1];
+  if (slot == 0 && threadIdx.x == 0) counts[b] = nkept;
+  if (slot >= nkept || slot >= max_comp) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* cont = (uint32_t*)smem;              // [GQ_NC] contour points (x | y << 16)
+  uint32_t* buf = cont + GQ_NC;                  // [GQ_NC] approximation output + slice stack; scratch before that
+  uint32_t* hull = buf + GQ_NC;                  // [GQ_NH]
+  const int lane = threadIdx.x;
+  const GeomComp cmp = comps[(size_t)b * max_comp + slot];
+  const int* L = Lb + (size_t)b * h * w;
+  const int* r = rows + ((size_t)b * max_comp + slot) * h * 2;
+  const int R = se.r;
+  GeomQuadOut o;
+  o.label = cmp.label; o.area = cmp.area;
+  for (int i = 0; i < 8; ++i) o.box[i] = 0;
+  o.cx = o.cy = 0.f; o.valid = 0; o.branch = 0; o.n_candidates = 0; o.contour_n = 0; o.hull_n = 0; o.flags = 0;
+  o.quality = 0.0; o.d1 = o.d2 = o.d_mean = 0.0;
+
+  // ---- row extremes of the dilated component: the dilation of the component's row extremes.  buf[y] = xl | xr << 16 (xl > xr: empty)
+  int y0 = 0x7FFFFFFF, y1 = -1;
+  for (int y = lane; y < h; y += 64) {
+    int xl = 0x7FFF, xr = -1;
+    for (int dy = -R; dy <= R; ++dy) {
+      const int yy = y + dy;
+      if ((unsigned)yy >= (unsigned)h) continue;
+      const int a = r[2 * yy], c = r[2 * yy + 1];
+      if (a > c) continue;
+      const int hwid = se.hw[dy + R];
+      xl = min(xl, max(a - hwid, 0));
+      xr = max(xr, min(c + hwid, w - 1));
+    }
+    if (xl <= xr) { y0 = min(y0, y); y1 = max(y1, y); buf[y] = (uint32_t)xl | ((uint32_t)xr << 16); }
+    else buf[y] = 0x0000FFFFu;               // xl = 65535 > xr = 0
+  }
+#pragma unroll
+  for (int ofs = 32; ofs > 0; ofs >>= 1) { y0 = min(y0, __shfl_xor(y0, ofs, 64)); y1 = max(y1, __shfl_xor(y1, ofs, 64)); }
+  // ---- hull (counter-clockwise on screen from the top-left: left chain down, right chain up), as k_geom_rect builds it
+  uint32_t* lch = cont;                          // chains in the contour buffer (free until the trace)
+  uint32_t* rch = cont + GQ_NC / 2;
+  int nl = 0, nr = 0;
+  for (int y = y0; y <= y1; ++y) {
+    const int px = (int)(buf[y] & 0xFFFFu);
+    while (nl >= 2) {
+      const uint32_t p1 = lch[nl - 1], p2 = lch[nl - 2];
+      const long c = (long)(gq_x(p1) - gq_x(p2)) * (y - gq_y(p2)) - (long)(gq_y(p1) - gq_y(p2)) * (px - gq_x(p2));
+      if (c >= 0) --nl; else break;
+    }
+    lch[nl++] = gq_pack(px, y);
+  }
+  for (int y = y1; y >= y0; --y) {
+    const int px = (int)(buf[y] >> 16);
+    while (nr >= 2) {
+      const uint32_t p1 = rch[nr - 1], p2 = rch[nr - 2];
+      const long c = (long)(gq_x(p1) - gq_x(p2)) * (y - gq_y(p2)) - (long)(gq_y(p1) - gq_y(p2)) * (px - gq_x(p2));
+      if (c >= 0) --nr; else break;
+    }
+    rch[nr++] = gq_pack(px, y);
+  }
+  const int x_start = (int)(buf[y0] & 0xFFFFu);          // raster-first pixel of the dilated component: (x_start, y0)
+  int first = 0, last = nr;
+  if (nr > 0 && rch[0] == lch[nl - 1]) first = 1;
+  if (last > first && rch[last - 1] == lch[0]) last -= 1;
+  int n = nl;
+  for (int i = first; i < last; ++i) lch[n++] = rch[i];    // n <= 2 h <= GQ_NC / 2: stays inside the left half ... or runs into rch[i' < i]: already consumed
+  int m = n;
+  if (n >= 3) {          // drop collinear junction points (the first vertex always stays); result into buf, then hull
+    m = 0;
+    for (int i = 0; i < n; ++i) {
+      const uint32_t A = lch[(i + n - 1) % n], Bp = lch[i], Cp = lch[(i + 1) % n];
+      const long c = (long)(gq_x(Bp) - gq_x(A)) * (gq_y(Cp) - gq_y(A)) - (long)(gq_y(Bp) - gq_y(A)) * (gq_x(Cp) - gq_x(A));
+      if (c != 0 || i == 0) buf[m++] = Bp;
+    }
+  } else {
+    for (int i = 0; i < n; ++i) buf[i] = lch[i];
+  }
+  // cv2.convexHull order: from the right-most (then bottom-most) vertex, clockwise on screen = the list above reversed and rotated
+  bool hull_ok = m <= GQ_NH;
+  if (!hull_ok) o.flags |= 2;
+  if (hull_ok) {
+    int st = 0;
+    for (int i = 1; i < m; ++i) {
+      const uint32_t a = buf[i], c = buf[st];
+      if (gq_x(a) > gq_x(c) || (gq_x(a) == gq_x(c) && gq_y(a) > gq_y(c))) st = i;
+    }
+    if (m >= 3) {
+      for (int i = lane; i < m; i += 64) { int q = st - i; if (q < 0) q += m; hull[i] = buf[q]; }
+    } else if (m == 2) {        // two points: descending (x, y)
+      hull[0] = buf[st]; hull[1] = buf[1 - st];
+    } else if (m == 1) {
+      hull[0] = buf[0];
+    }
+  }
+  o.hull_n = m;
+
+  // ---- external border of the dilated component (Suzuki-Abe as cv2 runs it); membership of the 8 neighbours of the current pixel
+  // from ONE cooperative load of the (2R + 3)^2 window of the label image
+  const int W3 = 2 * R + 3, ncell = W3 * W3;
+  unsigned long long sem0[8], sem1[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    unsigned long long a0 = 0ull, a1 = 0ull;
+    for (int dy = -R; dy <= R; ++dy)
+      for (int dx = -se.hw[dy + R]; dx <= se.hw[dy + R]; ++dx) {
+        const int cell = (gq_dy(s) + dy + R + 1) * W3 + (gq_dx(s) + dx + R + 1);
+        if (cell < 64) a0 |= 1ull << cell; else a1 |= 1ull << (cell - 64);
+      }
+    sem0[s] = a0; sem1[s] = a1;
+  }
+  const int c0y = lane / W3 - (R + 1), c0x = lane % W3 - (R + 1);
+  const int c1y = (lane + 64) / W3 - (R + 1), c1x = (lane + 64) % W3 - (R + 1);
+  auto neighbours = [&](int x, int y) -> int {       // bit s set: the neighbour in direction s belongs to the dilated component
+    bool in0 = false, in1 = false;
+    if (lane < ncell) {
+      const int yy = y + c0y, xx = x + c0x;
+      in0 = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w && L[(size_t)yy * w + xx] == cmp.root;
+    }
+    if (lane + 64 < ncell) {
+      const int yy = y + c1y, xx = x + c1x;
+      in1 = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w && L[(size_t)yy * w + xx] == cmp.root;
+    }
+    const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1);
+    int nb = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bool inside = (unsigned)(x + gq_dx(s)) < (unsigned)w && (unsigned)(y + gq_dy(s)) < (unsigned)h;   // the dilation exists inside the map only
+      nb |= ((inside && ((m0 & sem0[s]) | (m1 & sem1[s])) != 0ull) ? 1 : 0) << s;
+    }
+    return nb;
+  };
+  __builtin_amdgcn_s_waitcnt(0);                 // the hull's LDS traffic is done before the contour buffer is reused
+  __builtin_amdgcn_wave_barrier();
+  int cn = 0;
+  bool cont_ok = true;
+  {
+    const int x0 = x_start, yy0 = y0;
+    int nb = neighbours(x0, yy0);
+    int s = 4;
+    // first neighbour, clockwise from W: NW, N, NE, E, SE, S, SW
+    int found = -1;
+    for (int t = 0; t < 7; ++t) { s = (s - 1) & 7; if ((nb >> s) & 1) { found = s; break; } }
+    if (found < 0) {
+      cont[cn++] = gq_pack(x0, yy0);             // single pixel
+    } else {
+      const int x1 = x0 + gq_dx(s), yy1 = yy0 + gq_dy(s);
+      int x3 = x0, y3 = yy0, px = x0, py = yy0;
+      int prev_s = s ^ 4;
+      for (int step = 0;; ++step) {
+        if (step > 0) nb = neighbours(x3, y3);
+        // next border pixel: counter-clockwise from the direction after s
+        const int k = (s + 1) & 7;
+        const int rot = ((nb >> k) | (nb << (8 - k))) & 0xFF;
+        s = (k + __builtin_ctz(rot | 0x100)) & 7;
+        const int x4 = x3 + gq_dx(s), y4 = y3 + gq_dy(s);
+        if (s != prev_s) {
+          if (cn < GQ_NC) cont[cn] = gq_pack(px, py);
+          ++cn;
+          prev_s = s;
+        }
+        px += gq_dx(s); py += gq_dy(s);
+        if (x4 == x0 && y4 == yy0 && x3 == x1 && y3 == yy1) break;
+        if (step >= GQ_MAX_STEPS || rot == 0) { cont_ok = false; o.flags |= 4; break; }
+        x3 = x4; y3 = y4;
+        s = (s + 4) & 7;
+      }
+    }
+    if (cn > GQ_NC) { cont_ok = false; o.flags |= 1; }
+  }
+  o.contour_n = cn;
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- robust_quadrilateral_from_contour (:336-420)
+  GqBest best;
+  best.have = false; best.quality = 0.0; best.area = 0.0; best.ncand = 0;
+  const int npts = cont_ok ? cn : 0;
+  const bool enough = cn >= 4;                    // `if pts.shape[0] < 4: return None`
+  if (enough) {
+    GqQuad cand;
+    if (cont_ok && gq_try_poly(cont, npts, buf, &cand)) gq_offer(best, cand);
+    if (hull_ok && gq_try_poly(hull, m, buf, &cand)) gq_offer(best, cand);
+    o.branch = 1;
+    if (!best.have) {
+      o.branch = 2;
+      for (int which = 0; which < 2; ++which) {
+        const uint32_t* src = which == 0 ? cont : hull;
+        const int cnt = which == 0 ? npts : (hull_ok ? m : 0);
+        if (cnt == 0) continue;
+        const int k = gq_approx_closed(src, cnt, 0.01 * gq_arc_length(src, cnt), buf);
+        if (k > 4) {
+          for (int s = 0; s < (k < 12 ? k : 12); ++s) {
+            cand = gq_order_cw(gq_from(buf, s % k, (s + 1) % k, (s + 2) % k, (s + 3) % k));
+            if (gq_area(cand) > 10.0 && gq_convex(cand)) gq_offer(best, cand);
+          }
+        }
+      }
+    }
+    if (!best.have && hull_ok && m >= 1) {
+      o.branch = 3;
+      int iminx = 0, imaxx = 0, iminy = 0, imaxy = 0;
+      for (int i = 1; i < m; ++i) {              // first occurrence of every extreme, like np.argmin / np.argmax
+        if (gq_x(hull[i]) < gq_x(hull[iminx])) iminx = i;
+        if (gq_x(hull[i]) > gq_x(hull[imaxx])) imaxx = i;
+        if (gq_y(hull[i]) < gq_y(hull[iminy])) iminy = i;
+        if (gq_y(hull[i]) > gq_y(hull[imaxy])) imaxy = i;
+      }
+      cand = gq_order_cw(gq_from(hull, iminy, imaxx, imaxy, iminx));
+      if (gq_area(cand) > 10.0) gq_offer(best, cand);
+    }
+  }
+  o.n_candidates = best.ncand;
+  if (best.have) {
+    const GqQuad q = gq_order_cw(best.q);
+    o.valid = 1;
+    o.quality = best.quality;
+    int sx = 0, sy = 0;
+    for (int i = 0; i < 4; ++i) { o.box[2 * i] = (int)q.x[i]; o.box[2 * i + 1] = (int)q.y[i]; sx += o.box[2 * i]; sy += o.box[2 * i + 1]; }
+    o.cx = (float)((double)sx / 4.0);
+    o.cy = (float)((double)sy / 4.0);
+    double dmax = -1.0;
+    int i1 = 0, j1 = 1;
+    for (int a = 0; a < 4; ++a)
+      for (int c = a + 1; c < 4; ++c) {
+        const double ddx = (double)(o.box[2 * a] - o.box[2 * c]), ddy = (double)(o.box[2 * a + 1] - o.box[2 * c + 1]);
+        const double d = sqrt(ddx * ddx + ddy * ddy);
+        if (d > dmax) { dmax = d; i1 = a; j1 = c; }
+      }
+    int rest[2], nrr = 0;
+    for (int qi = 0; qi < 4; ++qi)
+      if (qi != i1 && qi != j1) rest[nrr++] = qi;
+    const double ex = (double)(o.box[2 * rest[0]] - o.box[2 * rest[1]]), ey = (double)(o.box[2 * rest[0] + 1] - o.box[2 * rest[1] + 1]);
+    o.d1 = dmax;
+    o.d2 = sqrt(ex * ex + ey * ey);
+    o.d_mean = 0.5 * (o.d1 + o.d2);
+  } else {
+    o.branch = 0;
+  }
+  if (lane == 0) out[(size_t)b * max_comp + slot] = o;
+}
+
 // ---------------------------------------------------------------------------------------------- host
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -527,16 +1038,8 @@ extern "C" int64_t vk_geom_workspace_bytes(const vk_geom_desc* d, int batch) {
   return (int64_t)geom_layout(d, batch).total;
 }
 
-extern "C" int vk_geom_minarearect(const vk_geom_desc* d, int batch, const float* prob, uint8_t* clean, vk_geom_det* dets, int* counts,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
-  int rc = geom_check(d, batch, "vk_geom_minarearect");
-  if (rc != VK_OK) return rc;
-  VK_CHECK_ARG(prob && clean && dets && counts && workspace, "vk_geom_minarearect: null buffer");
-  const GeomLayout g = geom_layout(d, batch);
-  VK_CHECK_ARG(workspace_bytes >= g.total, "vk_geom_minarearect: workspace too small (%zu < %zu)", workspace_bytes, g.total);
-  VK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "vk_geom_minarearect: workspace must be 256-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  char* ws = (char*)workspace;
+// steps 1-3 + clean mask + per-row extremes of the kept components, shared by both GUIs' post-processing
+static int geom_front(const vk_geom_desc* d, int batch, const float* prob, uint8_t* clean, char* ws, const GeomLayout& g, hipStream_t st) {
   const int h = d->h, w = d->w;
   const size_t n = (size_t)h * w;
   uint8_t* m0 = (uint8_t*)(ws + g.m0);
@@ -548,7 +1051,6 @@ extern "C" int vk_geom_minarearect(const vk_geom_desc* d, int batch, const float
   GeomComp* comps = (GeomComp*)(ws + g.comps);
   int* rows = (int*)(ws + g.rows);
   const dim3 grid2((w + 63) / 64, (h + 3) / 4, batch), blk(256);
-  vkh::ProfScope ps("geom_minarearect", st, 0.0, (double)batch * n * (4.0 + 1.0));
   // steps 1-2: threshold fused into the first morphological pass
   const GeomSE se = make_se(d->morph_kernel);
   const bool morph = d->morph_kernel > 1;
@@ -592,6 +1094,23 @@ extern "C" int vk_geom_minarearect(const vk_geom_desc* d, int batch, const float
     hipLaunchKernelGGL(k_geom_rows_init, dim3((unsigned)std::min<size_t>((pairs + 255) / 256, 4096)), blk, 0, st, pairs, rows);
   }
   hipLaunchKernelGGL(k_geom_clean_rows, grid2, blk, 0, st, h, w, (const int*)L, (const int*)area, d->max_components, clean, rows);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_geom_minarearect(const vk_geom_desc* d, int batch, const float* prob, uint8_t* clean, vk_geom_det* dets, int* counts,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = geom_check(d, batch, "vk_geom_minarearect");
+  if (rc != VK_OK) return rc;
+  VK_CHECK_ARG(prob && clean && dets && counts && workspace, "vk_geom_minarearect: null buffer");
+  const GeomLayout g = geom_layout(d, batch);
+  VK_CHECK_ARG(workspace_bytes >= g.total, "vk_geom_minarearect: workspace too small (%zu < %zu)", workspace_bytes, g.total);
+  VK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "vk_geom_minarearect: workspace must be 256-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  vkh::ProfScope ps("geom_minarearect", st, 0.0, (double)batch * d->h * d->w * (4.0 + 1.0));
+  rc = geom_front(d, batch, prob, clean, ws, g, st);
+  if (rc != VK_OK) return rc;
   // steps 4-5
   const size_t lds = (size_t)GEOM_MAX_H * 6 * sizeof(int);
   static bool attr_done = false;
@@ -599,8 +1118,37 @@ extern "C" int vk_geom_minarearect(const vk_geom_desc* d, int batch, const float
     VK_CHECK_HIP(hipFuncSetAttribute((const void*)k_geom_rect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_geom_rect, dim3(d->max_components, batch), blk, lds, st, h, d->max_components, (const int*)tot, (const GeomComp*)comps,
-                     (const int*)rows, (GeomRectOut*)dets, counts);
+  hipLaunchKernelGGL(k_geom_rect, dim3(d->max_components, batch), dim3(256), lds, st, d->h, d->max_components, (const int*)(ws + g.tot),
+                     (const GeomComp*)(ws + g.comps), (const int*)(ws + g.rows), (GeomRectOut*)dets, counts);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+extern "C" int vk_geom_quadrilateral(const vk_geom_desc* d, int fit_outset_px, int batch, const float* prob, uint8_t* clean, vk_geom_quad* dets,
+                                     int* counts, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = geom_check(d, batch, "vk_geom_quadrilateral");
+  if (rc != VK_OK) return rc;
+  VK_CHECK_ARG(prob && clean && dets && counts && workspace, "vk_geom_quadrilateral: null buffer");
+  VK_CHECK_ARG(fit_outset_px >= 0 && fit_outset_px <= 3, "vk_geom_quadrilateral: fit_outset_px %d outside 0..3", fit_outset_px);
+  VK_CHECK_ARG(d->w <= 16384 && d->h <= GEOM_MAX_H, "vk_geom_quadrilateral: map too large for 16-bit packed coordinates");
+  const GeomLayout g = geom_layout(d, batch);
+  VK_CHECK_ARG(workspace_bytes >= g.total, "vk_geom_quadrilateral: workspace too small (%zu < %zu)", workspace_bytes, g.total);
+  VK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "vk_geom_quadrilateral: workspace must be 256-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  vkh::ProfScope ps("geom_quadrilateral", st, 0.0, (double)batch * d->h * d->w * (4.0 + 1.0));
+  rc = geom_front(d, batch, prob, clean, ws, g, st);
+  if (rc != VK_OK) return rc;
+  // the fit dilates with getStructuringElement(MORPH_ELLIPSE, max(3, 2 * outset + 1)) (ui_infer_quadrilateral.py:476-479); 0 = no dilation
+  GeomSE se_fit = make_se(fit_outset_px > 0 ? std::max(3, 2 * fit_outset_px + 1) : 1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)k_geom_quad, hipFuncAttributeMaxDynamicSharedMemorySize, GQ_LDS));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_geom_quad, dim3(d->max_components, batch), dim3(64), (size_t)GQ_LDS, st, d->h, d->w, d->max_components,
+                     (const int*)(ws + g.tot), (const GeomComp*)(ws + g.comps), (const int*)(ws + g.rows), (const int*)(ws + g.L), se_fit,
+                     (GeomQuadOut*)dets, counts);
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }
