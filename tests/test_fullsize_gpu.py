@@ -82,7 +82,7 @@ def _engine_steps(O, x, y, steps, dtype, loss_scale=1.0):
 BN_KEYS = ("encoder.bn1.running_mean", "encoder.bn1.running_var", "decoder.blocks.4.conv2.1.running_mean", "decoder.blocks.4.conv2.1.running_var")
 
 
-def _compare(tag, eng, ora, yard, g_e, g_o, g_y, model, ref, steps, bn_bars=(2e-3, 2e-3, 2e-3, 2e-3), yard_stats=None):
+def _compare(tag, eng, ora, yard, g_e, g_o, g_y, model, ref, steps, bn_bars=(2e-3, 2e-3, 2e-3, 2e-3), yard_stats=None, cos_floor=0.90):
     print(f"[{tag}] losses (total, bce, dice) engine {eng} | fp32 oracle {ora}" + (f" | autocast oracle {yard}" if yard else ""))
     # step 1: total and both components
     for j, nm in enumerate(("total", "bce", "dice")):
@@ -105,19 +105,24 @@ def _compare(tag, eng, ora, yard, g_e, g_o, g_y, model, ref, steps, bn_bars=(2e-
         print(f"[{tag}] {k}: max|diff| / max|oracle| = {err:.2e}{note}")
         assert err <= bar, (k, err)
     assert int(sd_e["encoder.bn1.num_batches_tracked"]) == steps == int(sd_o["encoder.bn1.num_batches_tracked"])
-    # gradient direction, step 1
-    worst = 1.0
+    # gradient direction, step 1 (every parameter is printed before anything is asserted)
+    worst, bad = 1.0, []
     for k in NAMED:
         c_e = _cos(g_e[k], g_o[k])
         c_y = _cos(g_y[k], g_o[k]) if g_y is not None else None
         n_e = (g_e[k].double().norm() / (g_o[k].double().norm() + 1e-300)).item()
         print(f"[{tag}] grad {k}: cosine vs fp32 oracle engine {c_e:.4f}" + (f", autocast oracle {c_y:.4f}" if c_y is not None else "")
               + f"; norm ratio {n_e:.3f}")
-        if c_y is not None:
-            assert c_e >= c_y - 0.02, (k, c_e, c_y)
-        assert c_e >= 0.90, (k, c_e)
-        assert 0.8 <= n_e <= 1.25, (k, n_e)
+        fails = []
+        if c_y is not None and c_e < c_y - 0.02:
+            fails.append(("below the autocast yardstick", k, c_e, c_y))
+        if c_e < cos_floor:
+            fails.append(("below the floor", k, c_e, cos_floor))
+        if not 0.8 <= n_e <= 1.25:
+            fails.append(("norm", k, n_e))
         worst = min(worst, c_e)
+        bad += fails
+    assert not bad, bad
     return worst
 
 
@@ -136,7 +141,8 @@ def test_config3_bf16_bs32_512_three_steps_vs_oracle():
     t2 = time.perf_counter()
     eng, g_e, model = _engine_steps(O, x, y, 3, torch.bfloat16)
     print(f"[configs[2]] oracle fp32 3 steps {t1 - t0:.1f} s, autocast oracle 1 step {t2 - t1:.1f} s")
-    _compare("configs[2] bf16 bs32 512", eng, ora, yard, g_e, g_o, g_y, model, ref, 3, bn_bars=(1e-2, 1e-2, 3e-2, 3e-2), yard_stats=yard_stats)
+    _compare("configs[2] bf16 bs32 512", eng, ora, yard, g_e, g_o, g_y, model, ref, 3, bn_bars=(1e-2, 1e-2, 3e-2, 3e-2), yard_stats=yard_stats,
+             cos_floor=0.5)      # bf16 at random init: the reference's own mixed-precision arithmetic (CPU autocast) reaches 0.61 on the stem filter
 
 
 def test_config5_fp16_bs8_1024_one_step_vs_oracle():
