@@ -100,10 +100,11 @@ def conv_run(d, w, y, y1=None, split=0, acc=0, stats=None, plain=False):
 
 
 @pytest.fixture(params=["tile", "tile_alt1", "tile_alt2", "tile_alt3", "tile_alt7", "tile_alt8", "tile_alt2_plain", "tile_alt7_plain",
-                        "tile_persist", "tap"])
+                        "tile_alt2_stag", "tile_alt7_stag", "tile_persist", "tap"])
 def conv_path(request, monkeypatch):
     """tile: 3x3 stride-1 tile kernels with halo-pack weights (alt1/2/3/7/8: each tile shape of the K >= 128 class forced; the
-    8-wave shapes 2 and 7 run the software-pipelined kernel by default, `_plain` = their plain stage loop, VK_COL_PIPE=0);
+    8-wave shapes 2 and 7 run the software-pipelined kernel by default, `_plain` = their plain stage loop, VK_COL_PIPE=0,
+    `_stag` = the staggered form conv3x3_cols_kernel, VK_COL_PIPE=2);
     tile_persist: the persistent form of the K < 128 tile kernels forced onto the small test shapes, THREE workgroups walking all
     tiles (next tile's halo prefetched under the current tile's last stage and epilogue);
     tap: the tap-by-tap implicit-GEMM kernel with plain weights."""
@@ -113,6 +114,8 @@ def conv_path(request, monkeypatch):
         monkeypatch.delenv("VK_COL_ALT", raising=False)
     if request.param.endswith("_plain"):
         monkeypatch.setenv("VK_COL_PIPE", "0")
+    elif request.param.endswith("_stag"):
+        monkeypatch.setenv("VK_COL_PIPE", "2")
     else:
         monkeypatch.delenv("VK_COL_PIPE", raising=False)
     if request.param == "tile_persist":
@@ -958,3 +961,65 @@ def test_seg_metrics_refuses_cpu_and_bad_arguments():
     lib = L_.lib()
     assert lib.vk_seg_metrics(0, 64, 8, 8, 0, 0.5, 1e-7, 8, 24, 8, None) < 0
     assert lib.vk_seg_metrics(2, 64, 8, 8, 0, 0.5, 1e-7, 8, 24, 8, None) < 0       # workspace too small for two images
+
+
+# ------------------------------------------------------------------------------------------------ staggered K >= 128 tile kernel
+STAG_SHAPES = [
+    # N, H, sources [(C, up)], K, transposed-style flip handled by the dgrad entry below
+    ("l3_full", 32, 32, [(256, 0)], 256),
+    ("l2_full", 16, 64, [(128, 0)], 128),
+    ("l4_full", 32, 16, [(512, 0)], 512),
+    ("dec0c1", 8, 32, [(512, 1), (256, 0)], 256),
+    ("dec1c1", 4, 64, [(256, 1), (128, 0)], 128),
+    ("ragged", 3, 27, [(256, 0)], 384),
+]
+
+
+@pytest.mark.parametrize("dtn", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("shape", STAG_SHAPES, ids=[s[0] for s in STAG_SHAPES])
+def test_staggered_tile_kernel_is_bit_identical(shape, dtn, monkeypatch):
+    """conv3x3_cols_kernel (waves 4-7 half a stage behind waves 0-3, four weight stage buffers) against the pipelined kernel it replaces:
+    same operand order per accumulator -> the SAME BITS, at full layer sizes (every CU busy, hundreds of workgroups), forward with
+    BatchNorm statistics and the data-gradient direction, five repetitions each (a race between the two wave groups would show up as a
+    run-to-run difference)."""
+    _, N, H, srcs, K = shape
+    dt = DT[dtn]
+    if dtn == "f32" and N * H * H * K > 8 * 32 * 32 * 256:
+        N = max(1, N // 4)
+    lib = L_.lib()
+    ts = []
+    for i, (c, up) in enumerate(srcs):
+        t = D(gen(N, H >> up, H >> up, c, seed=10 + i).to(dt))
+        sc, sh = D(torch.rand(c, generator=torch.Generator().manual_seed(20 + i)) + 0.5), D(gen(c, seed=30 + i, scale=0.1))
+        ts.append(L_.vk_src(t.data_ptr(), c, up, sc.data_ptr(), sh.data_ptr(), 1))
+    s1 = ts[1] if len(ts) > 1 else L_.vk_src(None, 0, 0, None, None, 0)
+    Ct = sum(c for c, _ in srcs)
+    w = D((gen(K, 3, 3, Ct, seed=3) * 0.05).to(dt))
+    wt = D((gen(Ct, 3, 3, K, seed=4) * 0.05).to(dt))
+    dz = D(gen(N, H, H, K, seed=5).to(dt))
+    d_f = L_.vk_conv_desc(L_.dtype_code(dt), N, H, H, H, H, K, 3, 3, 1, 1, 0, ts[0], s1)
+    d_d = L_.vk_conv_desc(L_.dtype_code(dt), N, H, H, H, H, Ct, 3, 3, 1, 1, 1, L_.vk_src(dz.data_ptr(), K, 0, None, None, 0),
+                          L_.vk_src(None, 0, 0, None, None, 0))
+    assert lib.vk_conv_uses_halo_pack(C.byref(d_f)) and lib.vk_conv_uses_halo_pack(C.byref(d_d))
+    wf, wd_ = torch.empty_like(w), torch.empty_like(wt)
+    KEEP.extend([wf, wd_])
+    L_.check(lib.vk_halo_pack(L_.dtype_code(dt), K, Ct, w.data_ptr(), wf.data_ptr(), st()))
+    L_.check(lib.vk_halo_pack(L_.dtype_code(dt), Ct, K, wt.data_ptr(), wd_.data_ptr(), st()))
+
+    def run(pipe):
+        monkeypatch.setenv("VK_COL_PIPE", pipe)
+        y = torch.empty(N, H, H, K, device=dev(), dtype=dt)
+        dx = torch.empty(N, H, H, Ct, device=dev(), dtype=dt)
+        stats = torch.zeros(REPL * 2 * K, dtype=torch.float64, device=dev())
+        L_.check(lib.vk_conv_fwd_packed(C.byref(d_f), wf.data_ptr(), y.data_ptr(), None, 0, 0, stats.data_ptr(), st()))
+        L_.check(lib.vk_conv_fwd_packed(C.byref(d_d), wd_.data_ptr(), dx.data_ptr(), None, 0, 0, None, st()))
+        torch.cuda.synchronize()
+        return y, dx, stats.view(REPL, 2, K).sum(0)
+
+    y1, dx1, s1_ = run("1")
+    for rep in range(5):
+        y2, dx2, s2_ = run("2")
+        assert torch.equal(y1, y2), (rep, (y1.float() - y2.float()).abs().max().item())
+        assert torch.equal(dx1, dx2), (rep, (dx1.float() - dx2.float()).abs().max().item())
+        assert torch.allclose(s1_, s2_, rtol=1e-12, atol=1e-9)          # fp64 atomics: order-dependent in the last bits only
+    assert torch.isfinite(y1.float()).all() and y1.float().abs().max() > 0

@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--prof", action="store_true")
     ap.add_argument("--no-affine", action="store_true", help="sources without the BN+ReLU prologue (materialised activations)")
     ap.add_argument("--no-stats", action="store_true", help="forward without the BatchNorm partial sums")
+    ap.add_argument("--ab", default="", help="A/B in ONE process, interleaved rounds: NAME=v1,v2[,v3] sets the environment variable NAME "
+                                             "before each round of launches (the library reads its switches per launch)")
+    ap.add_argument("--rounds", type=int, default=5)
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
     dev = torch.device("cuda:0")
@@ -90,6 +93,30 @@ def main():
         }
         for op in a.ops.split(","):
             f = ops[op]
+            if a.ab:
+                import os
+                import statistics
+                var, vals = a.ab.split("=")
+                vals = vals.split(",")
+                res = {x: [] for x in vals}
+                for rnd_ in range(a.rounds + 1):
+                    for x in vals:
+                        os.environ[var] = x
+                        for _ in range(2):
+                            L_.check(f())
+                        torch.cuda.synchronize()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(a.reps):
+                            f()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        if rnd_:
+                            res[x].append(e0.elapsed_time(e1) * 1e3 / a.reps)
+                txt = "  ".join(f"{var}={x}: median {statistics.median(r):8.1f} min {min(r):8.1f} us ({flops / statistics.median(r) / 1e6 / 2500 * 100:5.1f} %)" for x, r in res.items())
+                print(f"{name:5s} {op:9s} H{H:<4d} C{Ctot:<4d} K{K:<4d} {txt}", flush=True)
+                os.environ.pop(var, None)
+                continue
             for _ in range(3):
                 L_.check(f())
             torch.cuda.synchronize()

@@ -1218,6 +1218,255 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_colq_kernel(const H
   halo_epilogue<T, TH, BN, TP, TC, NT, (BN <= 64 && TH == 16)>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
 }
 
+// ---- staggered form of the pipelined kernel (r03): the same tile, operand order and epilogue (bit-identical results), but the two
+// waves that share a SIMD run HALF A STAGE apart — see the comment in front of the main loop.  Four weight stage buffers.
+template <typename T, int TH, int BN, int WGM, int WGN>
+struct ColsCfg : ColCfg<T, TH, BN, WGM, WGN, true> {
+  using Base = ColCfg<T, TH, BN, WGM, WGN, true>;
+  static constexpr int MAIN = 2 * Base::A_BYTES + 4 * Base::B_BYTES;      // four weight stage buffers (see the kernel)
+  static constexpr int SMEM = MAIN > Base::EPI ? MAIN : Base::EPI;
+  static constexpr int DMAW = Base::NPIECE / Base::NW;           // LDS-DMA instructions per wave and stage
+  static_assert(Base::NPIECE % Base::NW == 0, "every wave must issue the same number of weight DMAs per stage (partial vmcnt wait)");
+  static_assert(DMAW >= 1 && DMAW <= 15, "vmcnt immediate");
+  static_assert(SMEM <= 160 * 1024, "LDS image exceeds the 160 KiB of a CU");
+};
+
+template <typename T, int TH, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_cols_kernel(const HaloParams p) {
+  using Cfg = ColsCfg<T, TH, BN, WGM, WGN>;
+  constexpr int EB = Cfg::EB, VE = Cfg::VE, CK = Cfg::CK, HPIX = Cfg::HPIX, NPV = Cfg::NPV, NT = Cfg::NT, NW = Cfg::NW;
+  constexpr int TP = Cfg::TP, TC = Cfg::TC, APS = Cfg::APS, NPIECE = Cfg::NPIECE;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Abuf = smem;
+  char* const Bbuf = smem + 2 * Cfg::A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int bt = blockIdx.x;
+  int ky = blockIdx.y;
+  if (p.kyn > 0) {                                           // see conv3x3_col_kernel
+    const int j = bt >> 3;
+    ky = j % p.kyn;
+    bt = (bt & 7) * (int)((gridDim.x / p.kyn) >> 3) + j / p.kyn;
+  } else if (p.kyn < 0) {
+    const int kn = -p.kyn, xcd = bt & 7;
+    ky = xcd % kn;
+    bt = (xcd / kn) * (int)(gridDim.x >> 3) + (bt >> 3);
+  } else if ((gridDim.x & 7) == 0) {
+    bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);
+  }
+  const int tx = bt % p.tiles_x;
+  bt /= p.tiles_x;
+  const int ty = bt % p.tiles_y;
+  const int n = bt / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const int n0 = ky * BN;
+
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.s0.ptr, p.s0.bytes);
+  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.s1.ptr ? p.s1.ptr : p.s0.ptr, p.s1.ptr ? p.s1.bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
+
+  const int hv = tid & 3;
+  int h_full[NPV], h_half[NPV];
+  const int Hh = p.H >> 1, Wh = p.W >> 1;
+#pragma unroll
+  for (int i = 0; i < NPV; ++i) {
+    const int hp = (tid >> 2) + i * (NT / 4);
+    const int hy = hp / 18, hx = hp - hy * 18;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = hp < HPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    h_full[i] = ok ? (n * p.H + y) * p.W + x : -1;
+    h_half[i] = ok ? (n * Hh + (y >> 1)) * Wh + (x >> 1) : -1;
+  }
+  u32x4_t areg[NPV];
+  float sc[VE], sh[VE];
+  bool aff = false, relu = false;
+
+  auto load_halo = [&](int cc) {
+    const int c = cc * CK;
+    const bool first = c < p.s0.C;
+    const HaloSrc& sd = first ? p.s0 : p.s1;
+    const int cl = (first ? c : c - p.s0.C) + hv * VE;
+    aff = sd.scale != nullptr;
+    relu = sd.relu != 0;
+    if (aff) {
+#pragma unroll
+      for (int j = 0; j < VE; j += 4) {
+        const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(sd.scale + cl + j);
+        const f32x4_t h4 = *reinterpret_cast<const f32x4_t*>(sd.shift + cl + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[j + e] = s4[e]; sh[j + e] = h4[e]; }
+      }
+    }
+    const bool up = sd.up != 0;
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int pix = up ? h_half[i] : h_full[i];
+      const uint32_t off = (uint32_t)(pix * sd.C + cl) * (uint32_t)EB;
+      if (first) areg[i] = buf_load16(rs0, pix >= 0 ? off : kOOB);
+      else areg[i] = buf_load16(rs1, pix >= 0 ? off : kOOB);
+    }
+  };
+  auto store_halo = [&](char* A) {
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int hp = (tid >> 2) + i * (NT / 4);
+      if (hp >= HPIX) continue;
+      u32x4_t v = areg[i];
+      if (aff) {
+        v = AffineRelu<T>::run(v, sc, sh, relu);
+        if (h_full[i] < 0) v = u32x4_t{0, 0, 0, 0};
+      }
+      *reinterpret_cast<u32x4_t*>(A + hp * APS + hv * 16) = v;
+    }
+  };
+
+  // weights of stage (chunk cc, filter column s) -> weight buffer s
+  const uint32_t slab_bytes = (uint32_t)p.K * 64u;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto dma_b = [&](int cc, int s, int buf) {
+#pragma unroll
+    for (int i = 0; i < Cfg::DMAW; ++i) {
+      const int pc = wave + i * NW;
+      const int r = pc / (BN / 16), sub = pc - r * (BN / 16);
+      const int tap = p.flip ? 8 - (3 * r + s) : 3 * r + s;
+      const uint32_t goff = (uint32_t)(cc * 9 + tap) * slab_bytes + (uint32_t)(n0 + sub * 16) * 64u;
+      char* dst = Bbuf + buf * Cfg::B_BYTES + (r * BN + sub * 16) * 64;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, lane16, goff, 0, 0);
+    }
+  };
+
+  const int wrow0 = (wave / WGN) * TP;
+  const int wch0 = (wave % WGN) * (TC * 16);
+  f32x4_t acc[TC][TP];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int li = lane & 15, kg = lane >> 4;
+  const int a_lane = (wrow0 * 18 + li) * APS + kg * 16;
+  const int b_lane = (wch0 + li) * 64 + ((kg ^ swz(li)) << 4);
+
+  // fragment sets: X = the TP + 2 halo rows of a stage, Wr = its three filter rows.  Rows 0..TP-1 and W0 of stage st + 1 are read in
+  // the second half (slot Y) of stage st, everything else under the MFMAs of the stage itself.
+  u32x4_t X[TP + 2], W0[TC], W1[TC], W2[TC];
+  auto rd = [](const char* q) { return *reinterpret_cast<const u32x4_t*>(q); };
+  auto mfma_row = [&](const u32x4_t (&Wr)[TC], int r) {
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) acc[a][b] = Mma<T>::run(Wr[a], X[b + r], acc[a][b]);
+  };
+  constexpr int NM = TC * TP * (sizeof(T) == 4 ? 4 : 1);       // MFMA instructions per filter row
+  constexpr int kWaitAll = 0x0070;                              // s_waitcnt vmcnt(0) lgkmcnt(0)  (expcnt untouched)
+  constexpr int kWaitLds = 0xC07F;                              // s_waitcnt lgkmcnt(0)
+
+  // ---- prologue (all waves together): first chunk's halo + the weights of its three stages into buffers 0..2
+  const int ksp = p.ksplit > 1 ? p.ksplit : 1;
+  const int c_begin = (int)((long)p.nchunks * blockIdx.z / ksp), c_end = (int)((long)p.nchunks * (blockIdx.z + 1) / ksp);
+  load_halo(c_begin);
+  dma_b(c_begin, 0, 0);
+  dma_b(c_begin, 1, 1);
+  dma_b(c_begin, 2, 2);
+  store_halo(Abuf);
+  __syncthreads();                                        // also drains the LDS-DMA (vmcnt(0))
+#pragma unroll
+  for (int h = 0; h < TP; ++h) X[h] = rd(Abuf + a_lane + h * (18 * APS));
+#pragma unroll
+  for (int a = 0; a < TC; ++a) W0[a] = rd(Bbuf + b_lane + (a * 16) * 64);
+
+  // ---- the stagger: every stage is two slots separated by workgroup barriers,
+  //        X: the stage's 3 * TC * TP MFMAs (with the fragment reads of filter rows 1 and 2 under them), then s_waitcnt vmcnt(0)
+  //        Y: everything that is not matrix work — next chunk's halo requests (s = 0) / BN+ReLU transform + LDS stores (s = 1), the
+  //           LDS-DMA of the weights three stages ahead, the first fragments of the next stage
+  //      and the second-dispatched half of the waves (4-7: each shares a SIMD with one of waves 0-3) enters the loop ONE BARRIER
+  //      later, so that on every SIMD one wave is in X while its partner is in Y: the matrix pipe always has exactly one customer and
+  //      the VALU / LDS-store / DMA-issue work of the partner sits beside those MFMAs instead of beside its own copy.
+  //      Slot t: early waves run X(st) at t = 2 st, Y(st) at 2 st + 1; late waves X(st) at 2 st + 1, Y(st) at 2 st + 2.
+  //   weights: stage st lives in buffer st % 4.  Its last reads are in X(st) (slots 2 st / 2 st + 1); the DMA of stage st + 4 into the
+  //      same buffer is issued in Y(st + 1) (slots 2 st + 3 / 2 st + 4) — behind a barrier that every reader has passed.  The DMA of
+  //      stage st + 3 issued in Y(st) is waited for (vmcnt(0)) by its issuing wave at the end of X(st + 1) (slots 2 st + 2 /
+  //      2 st + 3) and first read in Y(st + 2) (slots 2 st + 5 / 2 st + 6): a barrier lies between every wait and every read.
+  //   halo image: chunk cc + 1 is stored in Y(cc, 1) (slots 6 cc + 3 / 6 cc + 4) into the buffer chunk cc - 1 was last read from in
+  //      X(cc - 1, 2) (slots 6 cc - 2 / 6 cc - 1), and first read in Y(cc, 2) (slots 6 cc + 5 / 6 cc + 6).
+  const bool late = wave >= NW / 2;
+  if (late) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(kWaitLds);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  for (int cc = c_begin; cc < c_end; ++cc) {
+    const bool next_chunk = cc + 1 < c_end;
+    const char* const Acur = Abuf + ((cc - c_begin) & 1) * Cfg::A_BYTES + a_lane;
+    char* const Anext = Abuf + ((cc - c_begin + 1) & 1) * Cfg::A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int st = 3 * (cc - c_begin) + s;
+      const char* const As = Acur + s * APS;
+      const char* const Bs = Bbuf + (st & 3) * Cfg::B_BYTES + b_lane;
+      const bool more = s < 2 || next_chunk;
+      const char* const An = s < 2 ? Acur + (s + 1) * APS : Anext + a_lane;
+      const char* const Bn = Bbuf + ((st + 1) & 3) * Cfg::B_BYTES + b_lane;
+      // ---- slot X: the ten fragment reads of filter rows 1 and 2 first (40 LDS cycles), then the MFMAs in filter-row order — row 0
+      // runs on registers filled in the previous slot Y and covers the latency of those reads
+      X[TP] = rd(As + TP * (18 * APS));
+#pragma unroll
+      for (int a = 0; a < TC; ++a) W1[a] = rd(Bs + (BN + a * 16) * 64);
+      X[TP + 1] = rd(As + (TP + 1) * (18 * APS));
+#pragma unroll
+      for (int a = 0; a < TC; ++a) W2[a] = rd(Bs + (2 * BN + a * 16) * 64);
+      mfma_row(W0, 0);
+      mfma_row(W1, 1);
+      mfma_row(W2, 2);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * TC, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * NM, 0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(kWaitAll);                 // this wave's halo requests / weight DMAs of its previous slot Y have landed
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // ---- slot Y
+      if (next_chunk) {
+        if (s == 0) load_halo(cc + 1);                      // in front of the DMAs (vmcnt retires in order)
+        if (s == 1) store_halo(Anext);
+        dma_b(cc + 1, s, (st + 3) & 3);
+      }
+      if (more) {
+#pragma unroll
+        for (int h = 0; h < TP; ++h) X[h] = rd(An + h * (18 * APS));
+#pragma unroll
+        for (int a = 0; a < TC; ++a) W0[a] = rd(Bn + (a * 16) * 64);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(kWaitLds);                 // fragment reads returned, halo stores in LDS
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
+  if (!late) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                           // pairs with the late half's last slot
+    asm volatile("" ::: "memory");
+  }
+  __builtin_amdgcn_s_waitcnt(kWaitAll);
+  __syncthreads();                                          // every wave is done with the operand buffers: the epilogue reuses them
+
+  if (p.ksplit > 1) {
+    float* sl = p.slab + (size_t)blockIdx.z * ((size_t)p.N * p.H * p.W * p.K);
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) {
+        const int y = y0 + wrow0 + b, x = x0 + li, ch = n0 + wch0 + a * 16 + kg * 4;
+        if (y < p.H && x < p.W && ch < p.K) *reinterpret_cast<f32x4_t*>(sl + (((size_t)n * p.H + y) * p.W + x) * p.K + ch) = acc[a][b];
+      }
+    return;
+  }
+  halo_epilogue<T, TH, BN, TP, TC, NT, (BN <= 64 && TH == 16)>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
+}
+
 // ---- persistent form of the column-staged kernel for the K < 128 classes (layer1, decoder blocks 2-4: thousands of tiles, each a
 // prologue, 3-18 pipeline stages and an epilogue — HBM / latency-bound).  A workgroup walks tiles t = blockIdx.x, + gridDim.x, ...
 // and requests the NEXT tile's first halo chunk (global -> registers) during the last chunk of the current tile, so that the HBM
@@ -1744,18 +1993,23 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(size_t n4, int splits, co
   }
 }
 
-template <bool PIPE, typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW, int STR>
+template <int PIPE, typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW, int STR>
 struct ColLaunch {
   using Cfg = ColCfg<T, TH, BN, WGM, WGN, ADB, STR>;
   static const void* kernel() { return (const void*)conv3x3_col_kernel<T, TH, BN, WGM, WGN, ADB, MINW, STR>; }
 };
 template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW>
-struct ColLaunch<true, T, TH, BN, WGM, WGN, ADB, MINW, 1> {
+struct ColLaunch<1, T, TH, BN, WGM, WGN, ADB, MINW, 1> {
   using Cfg = ColqCfg<T, TH, BN, WGM, WGN>;
   static const void* kernel() { return (const void*)conv3x3_colq_kernel<T, TH, BN, WGM, WGN>; }
 };
+template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW>
+struct ColLaunch<2, T, TH, BN, WGM, WGN, ADB, MINW, 1> {
+  using Cfg = ColsCfg<T, TH, BN, WGM, WGN>;
+  static const void* kernel() { return (const void*)conv3x3_cols_kernel<T, TH, BN, WGM, WGN>; }
+};
 
-template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW, bool PIPE = false, int STR = 1>
+template <typename T, int TH, int BN, int WGM, int WGN, bool ADB, int MINW, int PIPE = 0, int STR = 1>
 static int launch_col(HaloParams p, hipStream_t st) {
   using Sel = ColLaunch<PIPE, T, TH, BN, WGM, WGN, ADB, MINW, STR>;
   using Cfg = typename Sel::Cfg;
@@ -1796,7 +2050,7 @@ static int launch_col(HaloParams p, hipStream_t st) {
     attr_done = true;
   }
   {
-    static const std::string tag_f = std::string(PIPE ? "colq_" : "col_") + (sizeof(T) == 4 ? "f32" : "16b") + "_t" + std::to_string(TH) + "_bn" +
+    static const std::string tag_f = std::string(PIPE == 2 ? "cols_" : PIPE == 1 ? "colq_" : "col_") + (sizeof(T) == 4 ? "f32" : "16b") + "_t" + std::to_string(TH) + "_bn" +
                                      std::to_string(BN) + "_w" + std::to_string(WGM * WGN) + (STR == 2 ? "_s2" : "");
     static const std::string tag_d = tag_f + "_dgrad";
     const double macs = (double)p.N * p.H * p.W * p.K * 9.0 * p.C;
@@ -1889,12 +2143,14 @@ static int col_select(const HaloParams& p, hipStream_t st) {
     // too few 16x16 tiles to fill the chip (layer4: 256 workgroups of 8x16x128): the same tile on EIGHT waves (4 rows x 32
     // channels each) — one workgroup per CU either way, but two waves per SIMD instead of one (L4 dgrad 46.6 -> 41.3 us)
     // the 8-wave tiles run software-pipelined (conv3x3_colq_kernel); VK_COL_PIPE=0 (diagnostic / tests): the plain stage loop
+    // VK_COL_PIPE=2: the staggered form (conv3x3_cols_kernel)
     const char* const pipe_s = getenv("VK_COL_PIPE");
-    const bool pipe = !(pipe_s && atoi(pipe_s) == 0);
+    const int pipe = pipe_s ? atoi(pipe_s) : 1;
     if (alt == 7 || (alt != 2 && tiles16 * kt < 256))
-      return pipe ? launch_col<T, 8, 128, 2, 4, true, 1, true>(p, st) : launch_col<T, 8, 128, 2, 4, true, 2>(p, st);
-    return pipe ? launch_col<T, 16, 128, 4, 2, true, 1, true>(p, st)       // 8 waves, 4 rows x 64 channels per wave
-                : launch_col<T, 16, 128, 4, 2, true, 2>(p, st);
+      return pipe == 2 ? launch_col<T, 8, 128, 2, 4, true, 1, 2>(p, st)
+             : pipe    ? launch_col<T, 8, 128, 2, 4, true, 1, 1>(p, st) : launch_col<T, 8, 128, 2, 4, true, 2>(p, st);
+    return pipe == 2 ? launch_col<T, 16, 128, 4, 2, true, 1, 2>(p, st)       // 8 waves, 4 rows x 64 channels per wave
+           : pipe    ? launch_col<T, 16, 128, 4, 2, true, 1, 1>(p, st) : launch_col<T, 16, 128, 4, 2, true, 2>(p, st);
   }
   if (p.K >= 64) return launch_small<T, 64>(p, st);
   // measured and rejected (r02): 32 x 16 pixel tiles for K <= 32 on the 256x256 / 512x512 maps (half the prologues / epilogues per
@@ -2041,9 +2297,9 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, 
     p.slab = nullptr;                                      // no split-K on this path
     p.slab_bytes = 0;
     switch (d->dtype) {
-      case VK_F32: return launch_col<float, 8, 128, 2, 4, false, 1, false, 2>(p, st);
-      case VK_BF16: return launch_col<bf16_t, 8, 128, 2, 4, false, 1, false, 2>(p, st);
-      case VK_F16: return launch_col<f16_t, 8, 128, 2, 4, false, 1, false, 2>(p, st);
+      case VK_F32: return launch_col<float, 8, 128, 2, 4, false, 1, 0, 2>(p, st);
+      case VK_BF16: return launch_col<bf16_t, 8, 128, 2, 4, false, 1, 0, 2>(p, st);
+      case VK_F16: return launch_col<f16_t, 8, 128, 2, 4, false, 1, 0, 2>(p, st);
     }
     return VK_ERR_ARG;
   }
