@@ -202,7 +202,8 @@ def main():
         red.timing = False
         tails = red.exposed_tail_ms()
         plan = next(iter(model._plans.values()))
-        dp_info = {"buckets_mb_fp32": [round((b1 - b0) * 4 / 1e6, 2) for b0, b1 in plan.buckets],
+        dp_info = {"policy": red.policy, "reserved_cus": red.reserved_cus,
+                   "buckets_mb_fp32": [round((b1 - b0) * 4 / 1e6, 2) for b0, b1 in plan.buckets],
                    "exposed_allreduce_tail_ms": [round(t, 3) for t in tails],
                    "note": "tail = time the compute stream waits for outstanding bucket all-reduces after its last backward "
                            "kernel and before AdamW (HIP events on the compute stream, rank 0, profile steps)"}
@@ -365,7 +366,8 @@ def main():
             "config": {"workload": f"unet_r34_{S} {args.dtype} {'train fwd+loss+bwd+AdamW' if args.mode == 'train' else 'eval forward'}, "
                                    f"bs={N}/GPU, BCE+Dice, synthetic {S}x{S} (BASELINE.json configs[{2 if args.mode == 'train' else 1}])",
                        "global_batch": world * N, "image_size": S,
-                       "parallelism": f"dp{world} (RCCL all-reduce of fp32 gradients, 10 buckets overlapped with backward)" if world > 1 else "single GPU"},
+                       "parallelism": (f"dp{world} (RCCL all-reduce of fp32 gradients over 10 backward-ordered buckets, issue policy "
+                                       f"{getattr(getattr(model, '_reducer', None), 'policy', '?')}: see parallel.py)") if world > 1 else "single GPU"},
             "conv_tflops": round((TRAIN_GFLOP_PER_IMG_512 if args.mode == "train" else FWD_GFLOP_PER_IMG_512) * (S / 512) ** 2 * ips / 1e3, 2),
             "last_loss": last,
             "api_path_ms_per_step": None if api_ms is None else round(api_ms, 3),

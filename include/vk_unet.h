@@ -10,6 +10,7 @@
  *   vk_unet_loss .............................. bce(logits,y)+dice(logits,y) train.py:438, 513 (600-601)
  *   vk_unet_backward .......................... loss.backward()              train.py:443, 448
  *   vk_seg_metrics ............................ dice_coef / iou_coef (validate) train.py:230-281, 518-522
+ *   vk_comm_* / vk_allreduce_bucket ........... (no reference counterpart: the 8-GPU data-parallel exchange)
  *   vk_adamw_step ............................. optimizer.step()/zero_grad   train.py:428, 449 (606)
  *   vk_amp_check_inf / vk_amp_unscale_check /
  *   vk_adamw_step_amp ......................... GradScaler unscale + inf check + skipped step  train.py:441-445 (610-611)
@@ -61,6 +62,11 @@ int vk_has_gfx950_code(void);
  * every SIMD of the chip, `iters` x 8 MFMAs each — what the matrix pipes deliver at the clock the chip sustains under that load.
  * FLOPs issued = *flops_out (when not null); time it with events on `stream`.  sink: 4 floats of device scratch. */
 int vk_probe_mfma_rate(int iters, int waves_per_simd, float* sink, double* flops_out, void* stream);
+/* Data-parallel runs: while a communication library's kernels hold compute units, launches sized to exactly one workgroup per CU
+ * (the weight-gradient kernels: <= 256 persistent workgroups that split the pixel tiles among themselves) fall into a second round.
+ * n > 0 sizes those grids for (CUs - n) instead; 0 (default) restores the full chip.  Process-wide, read per launch; the Python host
+ * sets it only for the backward stages that overlap a collective (parallel.py).  Returns the previous value. */
+int vk_set_reserved_cus(int n);
 /* Measurement aid (tests/diag/cu_hold.py): occupy compute units the way a communication library's channel kernels do while a step
  * runs on another stream.  Launches `workgroups` workgroups of `threads` threads (64..1024) with `lds_bytes` of LDS each
  * (lds_bytes = 163840 takes a whole CU: no tile kernel fits beside it; a small value lets other workgroups co-reside and only
@@ -449,6 +455,30 @@ int vk_unet_loss(vk_unet* h, const float* logits, const float* target, float* lo
  * accumulated into the flat grad buffer (caller zeroes it once per step, e.g. via vk_unet_zero_grad). */
 int vk_unet_backward(vk_unet* h, const float* dlogits, int stage_begin, int stage_end, void* stream);
 int vk_unet_zero_grad(vk_unet* h, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel collectives for a host that is not PyTorch (SURVEY.md 8(b) "DP", 8(e)): RCCL over xGMI behind plain C.  The reference
+ * is single-process; this is the new capability's C boundary.  One process per GPU (call hipSetDevice first); rank 0 creates the id
+ * and hands its VK_COMM_ID_BYTES to the other ranks by any out-of-band means (file, socket, MPI); vk_comm_init is collective.
+ * A data-parallel step below the C boundary:
+ *     vk_unet_zero_grad; vk_unet_forward; vk_unet_loss;
+ *     for stage s in 0 .. num_buckets-1:  vk_unet_backward(h, NULL, s, s + 1, compute_stream)
+ *     [event on compute_stream -> comm_stream waits]  vk_allreduce_bucket(comm, grads + b0, b1 - b0, comm_stream) for the finished
+ *         buckets — per bucket, or (recommended, see parallel.py / DESIGN.md section 5) ONE call over buckets 0..8, which are contiguous,
+ *         once stage 8 is done, then bucket 9 after the last stage;
+ *     [compute_stream waits for comm_stream]  vk_adamw_step(..., inv_scale = 1 / world, ...)
+ * librccl.so is opened on first use; VK_ERR_STATE when it is absent.
+ * ---------------------------------------------------------------------------------------------- */
+#define VK_COMM_ID_BYTES 128
+typedef struct vk_comm vk_comm;
+int vk_comm_unique_id(void* id_out /* VK_COMM_ID_BYTES */);
+int vk_comm_init(int rank, int world, const void* id, vk_comm** out);
+int vk_comm_world(const vk_comm* c);
+/* in-place SUM over all ranks of `count` fp32 gradients, enqueued on `stream` (ncclAllReduce) */
+int vk_allreduce_bucket(vk_comm* c, float* grads, size_t count, void* stream);
+/* in-place broadcast of `bytes` bytes from rank `root` (parameters / BatchNorm buffers at start, ncclBroadcast) */
+int vk_comm_broadcast(vk_comm* c, void* buf, size_t bytes, int root, void* stream);
+int vk_comm_destroy(vk_comm* c);
 
 /* debugging / parity: pointer + shape of a named intermediate ("z:encoder.layer1.0.conv1", "out:encoder.layer1.0", ...) */
 int vk_unet_debug_tensor(const vk_unet* h, const char* name, void** ptr, int dims_nhwc[4]);

@@ -1023,3 +1023,31 @@ def test_staggered_tile_kernel_is_bit_identical(shape, dtn, monkeypatch):
         assert torch.equal(dx1, dx2), (rep, (dx1.float() - dx2.float()).abs().max().item())
         assert torch.allclose(s1_, s2_, rtol=1e-12, atol=1e-9)          # fp64 atomics: order-dependent in the last bits only
     assert torch.isfinite(y1.float()).all() and y1.float().abs().max() > 0
+
+
+# ------------------------------------------------------------------------------------------------ DP collectives behind the C ABI
+def test_comm_c_abi_single_rank():
+    """vk_comm_* / vk_allreduce_bucket (RCCL behind plain C, SURVEY.md 8(b) "DP"): a one-rank communicator on this GPU — id, init,
+    in-place all-reduce (sum over one rank = identity, and the call really runs: the buffer is read and written by RCCL's kernel),
+    broadcast, destroy.  More ranks need more GPUs (RCCL refuses two ranks on one device); the multi-rank arithmetic is covered by the
+    gloo tests of the Python reducer, which issues the same collectives."""
+    lib = L_.lib()
+    ident = C.create_string_buffer(128)
+    L_.check(lib.vk_comm_unique_id(ident), "vk_comm_unique_id")
+    assert any(ident.raw)
+    h = C.c_void_p()
+    L_.check(lib.vk_comm_init(0, 1, ident, C.byref(h)), "vk_comm_init")
+    try:
+        assert lib.vk_comm_world(h) == 1
+        g = D(gen(1 << 20, seed=9))
+        ref = g.clone()
+        L_.check(lib.vk_allreduce_bucket(h, g.data_ptr(), g.numel(), st()), "vk_allreduce_bucket")
+        b = D(gen(4099, seed=10))
+        refb = b.clone()
+        L_.check(lib.vk_comm_broadcast(h, b.data_ptr(), b.numel() * 4, 0, st()), "vk_comm_broadcast")
+        torch.cuda.synchronize()
+        assert torch.equal(g, ref) and torch.equal(b, refb)
+        assert lib.vk_allreduce_bucket(h, None, 4, st()) < 0 and lib.vk_comm_broadcast(h, b.data_ptr(), 16, 3, st()) < 0
+    finally:
+        L_.check(lib.vk_comm_destroy(h), "vk_comm_destroy")
+    assert lib.vk_comm_init(2, 2, ident, C.byref(h)) < 0          # rank outside [0, world)

@@ -61,6 +61,20 @@ def _worker(rank, world, port, q):
     dist.all_gather(gathered, local)
     want = torch.stack(gathered).mean(0)
     ok_avg = torch.allclose(flat, want, rtol=1e-6, atol=1e-9)
+    # the three issue policies reduce the same buffer to the same bits; "deferred" sends buckets 0..8 as ONE collective once stage 8 is
+    # done and bucket 9 afterwards, "tail" one collective in finish(), "eager" ten
+    issued = {}
+    for pol in ("eager", "deferred", "tail"):
+        fp = local.clone()
+        rp = vk.GradientReducer(lambda fp=fp: fp, world_size=world, scale_grads=True, policy=pol, defer_until=9)
+        counts = []
+        for i, rg in enumerate(ranges):
+            rp.bucket_ready(i, rg)
+            counts.append(len(rp._handles))
+        rp.finish()
+        issued[pol] = counts
+        ok_avg = ok_avg and torch.equal(fp, flat) and not rp.in_flight
+    ok_avg = ok_avg and issued["eager"] == list(range(1, 11)) and issued["deferred"] == [0] * 8 + [1, 2] and issued["tail"] == [0] * 10
     # folded scaling variant: SUM only, optimizer applies 1/world
     flat2 = local.clone()
     red2 = vk.GradientReducer(lambda: flat2, world_size=world, scale_grads=False)

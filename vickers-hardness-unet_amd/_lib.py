@@ -81,6 +81,7 @@ SIGNATURES = {
     "vk_last_error_string": (C.c_char_p, []),
     "vk_has_gfx950_code": (ci, []),
     "vk_probe_mfma_rate": (ci, [ci, ci, vp, P(C.c_double), vp]),
+    "vk_set_reserved_cus": (ci, [ci]),
     "vk_debug_hold_cus": (ci, [ci, ci, ci, ci, vp, sz, vp, vp]),
     "vk_debug_set_stamp_buffer": (ci, [vp]),
     "vk_prof_enable": (ci, [ci]),
@@ -143,6 +144,12 @@ SIGNATURES = {
     "vk_unet_backward": (ci, [vp, vp, ci, ci, vp]),
     "vk_unet_zero_grad": (ci, [vp, vp]),
     "vk_unet_debug_tensor": (ci, [vp, C.c_char_p, P(vp), P(ci * 4)]),
+    "vk_comm_unique_id": (ci, [vp]),
+    "vk_comm_init": (ci, [ci, ci, vp, P(vp)]),
+    "vk_comm_world": (ci, [vp]),
+    "vk_allreduce_bucket": (ci, [vp, vp, sz, vp]),
+    "vk_comm_broadcast": (ci, [vp, vp, sz, ci, vp]),
+    "vk_comm_destroy": (ci, [vp]),
 }
 
 _lib = None

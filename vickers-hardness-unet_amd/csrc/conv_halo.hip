@@ -1363,6 +1363,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_cols_kernel(const H
   constexpr int kWaitAll = 0x0070;                              // s_waitcnt vmcnt(0) lgkmcnt(0)  (expcnt untouched)
   constexpr int kWaitLds = 0xC07F;                              // s_waitcnt lgkmcnt(0)
 
+#ifdef VK_STAMP
+  unsigned long long t_begin, t_pro, tkX = 0, tkW = 0, tkB1 = 0, tkY = 0, tkB2 = 0;
+  VK_T(t_begin)
+#endif
   // ---- prologue (all waves together): first chunk's halo + the weights of its three stages into buffers 0..2
   const int ksp = p.ksplit > 1 ? p.ksplit : 1;
   const int c_begin = (int)((long)p.nchunks * blockIdx.z / ksp), c_end = (int)((long)p.nchunks * (blockIdx.z + 1) / ksp);
@@ -1391,6 +1395,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_cols_kernel(const H
   //      2 st + 3) and first read in Y(st + 2) (slots 2 st + 5 / 2 st + 6): a barrier lies between every wait and every read.
   //   halo image: chunk cc + 1 is stored in Y(cc, 1) (slots 6 cc + 3 / 6 cc + 4) into the buffer chunk cc - 1 was last read from in
   //      X(cc - 1, 2) (slots 6 cc - 2 / 6 cc - 1), and first read in Y(cc, 2) (slots 6 cc + 5 / 6 cc + 6).
+  VK_T(t_pro)
   const bool late = wave >= NW / 2;
   if (late) {
     asm volatile("" ::: "memory");
@@ -1410,6 +1415,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_cols_kernel(const H
       const bool more = s < 2 || next_chunk;
       const char* const An = s < 2 ? Acur + (s + 1) * APS : Anext + a_lane;
       const char* const Bn = Bbuf + ((st + 1) & 3) * Cfg::B_BYTES + b_lane;
+#ifdef VK_STAMP
+      unsigned long long t0, t1, t2, t3, t4, t5;
+#endif
+      VK_T(t0)
       // ---- slot X: the ten fragment reads of filter rows 1 and 2 first (40 LDS cycles), then the MFMAs in filter-row order — row 0
       // runs on registers filled in the previous slot Y and covers the latency of those reads
       X[TP] = rd(As + TP * (18 * APS));
@@ -1423,26 +1432,39 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_cols_kernel(const H
       mfma_row(W2, 2);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * TC, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 3 * NM, 0);
+      VK_T(t1)
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(kWaitAll);                 // this wave's halo requests / weight DMAs of its previous slot Y have landed
+      VK_T(t2)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      // ---- slot Y
-      if (next_chunk) {
-        if (s == 0) load_halo(cc + 1);                      // in front of the DMAs (vmcnt retires in order)
-        if (s == 1) store_halo(Anext);
-        dma_b(cc + 1, s, (st + 3) & 3);
-      }
+      VK_T(t3)
+      // ---- slot Y: the first fragments of the next stage are requested FIRST (their latency runs under the halo / DMA work below);
+      // p.dbg & 16 (timing experiment, results unchanged): this slot at raised priority, so that its few vector instructions are
+      // not queued behind the partner wave's MFMA stream
+      if (p.dbg & 16) __builtin_amdgcn_s_setprio(1);
       if (more) {
 #pragma unroll
         for (int h = 0; h < TP; ++h) X[h] = rd(An + h * (18 * APS));
 #pragma unroll
         for (int a = 0; a < TC; ++a) W0[a] = rd(Bn + (a * 16) * 64);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (next_chunk) {
+        if (s == 0) load_halo(cc + 1);                      // in front of the DMAs (vmcnt retires in order)
+        if (s == 1) store_halo(Anext);
+        dma_b(cc + 1, s, (st + 3) & 3);
+      }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(kWaitLds);                 // fragment reads returned, halo stores in LDS
+      if (p.dbg & 16) __builtin_amdgcn_s_setprio(0);
+      VK_T(t4)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      VK_T(t5)
+#ifdef VK_STAMP
+      tkX += t1 - t0; tkW += t2 - t1; tkB1 += t3 - t2; tkY += t4 - t3; tkB2 += t5 - t4;
+#endif
     }
   }
   if (!late) {
@@ -1451,6 +1473,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_cols_kernel(const H
     asm volatile("" ::: "memory");
   }
   __builtin_amdgcn_s_waitcnt(kWaitAll);
+#ifdef VK_STAMP
+  {
+    unsigned long long t_end;
+    VK_T(t_end)
+    if (p.stamps && lane == 0) {
+      unsigned long long* o = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+      o[0] = tkX; o[1] = tkW; o[2] = tkB1; o[3] = tkY; o[4] = tkB2; o[5] = t_pro - t_begin; o[6] = t_end - t_begin; o[7] = 3 * (c_end - c_begin);
+    }
+  }
+#endif
   __syncthreads();                                          // every wave is done with the operand buffers: the epilogue reuses them
 
   if (p.ksplit > 1) {

@@ -96,6 +96,16 @@ extern "C" int vk_prof_collect(char* buf, size_t buflen) {
   return (int)off;
 }
 
+namespace vkh {
+static std::atomic<int> g_reserved_cus{0};
+int reserved_cus() { return g_reserved_cus.load(std::memory_order_relaxed); }
+}  // namespace vkh
+extern "C" int vk_set_reserved_cus(int n) {
+  if (n < 0) n = 0;
+  if (n > 192) n = 192;
+  return vkh::g_reserved_cus.exchange(n);
+}
+
 extern "C" int vk_version(void) { return VK_ABI_VERSION; }
 extern "C" const char* vk_last_error_string(void) { return vkh::g_err; }
 

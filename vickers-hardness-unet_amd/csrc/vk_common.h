@@ -254,6 +254,7 @@ inline vk::FastDiv make_fastdiv(uint32_t d) {
   return f;
 }
 void set_error(const char* fmt, ...);
+int reserved_cus();          // vk_set_reserved_cus: compute units to leave to a concurrent communication kernel (0 = none)
 
 // Optional per-launch timing with HIP events on the launch stream (vk_prof_enable / vk_prof_collect).
 // tag: kernel family; flops / bytes: ALGORITHMIC work of this launch (DESIGN.md "roofline accounting").

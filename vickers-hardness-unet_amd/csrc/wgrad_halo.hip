@@ -419,7 +419,9 @@ static int launch_wh(WhParams p, size_t slab_bytes, hipStream_t st) {
   if (kt * ct > wh_max_combo()) return VK_ERR_UNSUPPORTED;      // deep layers: output tile traffic would dominate
   // every workgroup ends with KT*CT*9 fp32 atomics: give it at least ~6 pixel tiles of work
   const char* e_blk = getenv("VK_WH_BLOCKS");
-  const int target_blocks = e_blk ? atoi(e_blk) : (WS ? (KT >= 32 ? 512 : 1024) : 256);       // non-WS: LDS allows exactly one workgroup per CU
+  // non-WS: LDS allows exactly one workgroup per CU; with compute units reserved for a concurrent collective (vk_set_reserved_cus)
+  // the persistent grid is sized for the rest, instead of stranding its last workgroups behind a full round
+  const int target_blocks = e_blk ? atoi(e_blk) : (WS ? (KT >= 32 ? 512 : 1024) : 256 - vkh::reserved_cus());
   int splits = target_blocks / (kt * ct);     // never exceed the target: a second round of workgroups costs a full round
   if (splits > p.ntiles / 6) splits = p.ntiles / 6;
   if (splits < 1) splits = 1;

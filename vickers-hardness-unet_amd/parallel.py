@@ -12,6 +12,20 @@ RCCL's own stream behind an event, overlapping the remaining backward kernels.  
 all handles before the optimizer runs.  The 1/world factor is folded into the AdamW kernel
 (``FusedAdamW.grad_inv_scale``) or applied by ``scale_grads=True``.
 
+WHEN the collectives are issued is a policy (``GradientReducer.policy``), because on this chip it decides what they cost: the
+K >= 128 tile kernels and the weight-gradient kernels launch exactly one workgroup per compute unit (<= 256 workgroups, 111-160 KiB
+of LDS each), and a communication kernel that holds even 8 CUs while they run pushes those launches into a second round
+(tests/diag/cu_hold.py, profiles/r03/cu_hold*.log: +35 % step time with 8-32 CUs held for the whole step, +13-15 % with co-resident
+streaming workgroups).
+  * ``"eager"``    — every bucket is reduced as soon as its stage has finished (maximal overlap, r01/r02 behaviour);
+  * ``"deferred"`` — (default) buckets 0 .. defer_until-1 are contiguous in the flat buffer (the bucket table runs from its tail to its
+                     head) and are reduced by ONE collective issued when stage defer_until-1 has finished, i.e. 99 % of the bytes
+                     travel under the last stage (layer 1 + stem: HBM-bound kernels with thousands of workgroups, which lose a few
+                     per cent to held CUs, not a whole round); the last, tiny bucket follows at the end;
+  * ``"tail"``     — one collective over the whole buffer after the last stage (no overlap: the robust lower bound).
+``reserved_cus`` > 0 additionally caps the grids of the one-workgroup-per-CU weight-gradient kernels at (CUs - reserved_cus) while
+collectives are in flight (vk_set_reserved_cus).
+
 The class only needs a flat gradient tensor and bucket ranges, so the same code is exercised on CPU
 with the gloo backend (tests/test_parallel_cpu.py)."""
 from __future__ import annotations
@@ -23,8 +37,11 @@ import torch.distributed as dist
 
 
 class GradientReducer:
+    POLICIES = ("eager", "deferred", "tail")
+
     def __init__(self, flat_grads_getter, world_size: Optional[int] = None, process_group=None,
-                 scale_grads: bool = False, force: bool = False):
+                 scale_grads: bool = False, force: bool = False, policy: str = "deferred", defer_until: int = 9,
+                 reserved_cus: int = 0):
         self._get = flat_grads_getter
         self.pg = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
@@ -34,10 +51,35 @@ class GradientReducer:
         self.enabled = self.world > 1 or force        # force: run the collectives even with one rank (testing)
         self.timing = False                           # bench.py: bracket the wait for the collectives with two events
         self._tail_events: List = []
+        if policy not in self.POLICIES:
+            raise ValueError("policy must be one of %s" % (self.POLICIES,))
+        self.policy = policy
+        self.defer_until = int(defer_until)           # "deferred": stages [0, defer_until) travel as one collective
+        self.reserved_cus = int(reserved_cus)
+        self._held: List[Tuple[int, int]] = []        # finished, not yet issued buckets
+        self.in_flight = False                        # a collective has been issued and not yet waited for
 
     @property
     def inv_world(self) -> float:
         return 1.0 / self.world
+
+    def _issue(self, b0: int, b1: int):
+        view = self._get()[b0:b1]
+        self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self._ranges.append((b0, b1))
+        self.in_flight = True
+
+    def _flush_held(self):
+        """One collective per maximal contiguous run of the held buckets (the engine's table is one run)."""
+        runs: List[List[int]] = []
+        for b0, b1 in sorted(self._held):
+            if runs and runs[-1][1] == b0:
+                runs[-1][1] = b1
+            else:
+                runs.append([b0, b1])
+        for b0, b1 in runs:
+            self._issue(b0, b1)
+        self._held.clear()
 
     def bucket_ready(self, index: int, rng: Tuple[int, int]):
         if not self.enabled:
@@ -45,11 +87,16 @@ class GradientReducer:
         b0, b1 = rng
         if b1 <= b0:
             return
-        view = self._get()[b0:b1]
-        self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-        self._ranges.append(rng)
+        if self.policy == "eager":
+            self._issue(b0, b1)
+            return
+        self._held.append((b0, b1))
+        if self.policy == "deferred" and index >= self.defer_until - 1:
+            self._flush_held()                        # stage defer_until-1 done: everything so far goes out; later buckets one by one
 
     def finish(self):
+        if self.enabled and self._held:
+            self._flush_held()
         timed = self.timing and self.enabled and self._handles and torch.cuda.is_available()
         if timed:      # exposed tail = what the compute stream still has to wait for after its last backward kernel
             e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -65,7 +112,7 @@ class GradientReducer:
                 g[b0:b1].mul_(self.inv_world)
         self._handles.clear()
         self._ranges.clear()
-
+        self.in_flight = False
 
     def exposed_tail_ms(self) -> List[float]:
         """Per step: time the compute stream waited for outstanding all-reduces after the last backward kernel (needs
@@ -100,10 +147,16 @@ def broadcast_model(model, src: int = 0, process_group=None):
     model.mark_weights_dirty()
 
 
-def make_data_parallel(model, optimizer=None, process_group=None, force: bool = False) -> GradientReducer:
-    """Attach a GradientReducer to ``model``; with a FusedAdamW the averaging is folded into its kernel."""
+def make_data_parallel(model, optimizer=None, process_group=None, force: bool = False, policy: Optional[str] = None,
+                       reserved_cus: Optional[int] = None) -> GradientReducer:
+    """Attach a GradientReducer to ``model``; with a FusedAdamW the averaging is folded into its kernel.  ``policy`` / ``reserved_cus``
+    default to the environment (VK_DP_POLICY = eager | deferred | tail, VK_DP_RESERVED_CUS = n) and then to "deferred" / 0."""
+    import os
     fold = optimizer is not None and hasattr(optimizer, "grad_inv_scale")
-    red = GradientReducer(lambda: model.flat_grads, process_group=process_group, scale_grads=not fold, force=force)
+    policy = policy or os.environ.get("VK_DP_POLICY", "deferred")
+    reserved_cus = int(os.environ.get("VK_DP_RESERVED_CUS", "0")) if reserved_cus is None else reserved_cus
+    red = GradientReducer(lambda: model.flat_grads, process_group=process_group, scale_grads=not fold, force=force, policy=policy,
+                          reserved_cus=reserved_cus)
     if fold:
         optimizer.grad_inv_scale = red.inv_world
     model._reducer = red

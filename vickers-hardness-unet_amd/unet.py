@@ -334,10 +334,18 @@ class Unet(nn.Module):
         if red is not None and getattr(red, "enabled", True) and not getattr(plan, "_side_off", False):
             check(L.vk_unet_set_side_stream(plan.h, 0), "vk_unet_set_side_stream")    # see include/vk_unet.h
             plan._side_off = True
-        for s in range(plan.nbuckets):
-            check(L.vk_unet_backward(plan.h, _lib.ptr(dlogits), s, s + 1, st), "vk_unet_backward")
-            if red is not None:
-                red.bucket_ready(s, plan.buckets[s])
+        capped = False
+        try:
+            for s in range(plan.nbuckets):
+                if red is not None and red.reserved_cus > 0 and red.in_flight and not capped:
+                    L.vk_set_reserved_cus(red.reserved_cus)      # collectives share the chip from here on: see parallel.py
+                    capped = True
+                check(L.vk_unet_backward(plan.h, _lib.ptr(dlogits), s, s + 1, st), "vk_unet_backward")
+                if red is not None:
+                    red.bucket_ready(s, plan.buckets[s])
+        finally:
+            if capped:
+                L.vk_set_reserved_cus(0)
         if red is not None:
             red.finish()
 
