@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_colq_kernel(const H
       if (hp >= HPIX) continue;
       u32x4_t v = areg[i];
       if (aff) {
-        v = AffineRelu<T>::run(v, sc, sh, relu);
+        v = (p.dbg & 32) ? AffineReluScalar<T>::run(v, sc, sh, relu) : AffineRelu<T>::run(v, sc, sh, relu);
         if (h_full[i] < 0) v = u32x4_t{0, 0, 0, 0};
       }
       *reinterpret_cast<u32x4_t*>(A + hp * APS + hv * 16) = v;

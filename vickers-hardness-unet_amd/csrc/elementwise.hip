@@ -52,12 +52,17 @@ __global__ __launch_bounds__(256) void k_bn_finalize(int C, int train, const dou
     s1 = stats[(size_t)r * 2 * C + c];
     s2 = stats[(size_t)r * 2 * C + C + c];
   }
+  // the finishing lane's other operands are requested NOW, beside the statistics, not one dependent round trip after the reduction
+  // (this launch sits on the critical path between a convolution and its consumer 46 times per step)
+  const bool fin = r == 0 && c < C;
+  const float ga = fin ? gamma[c] : 0.f, be = fin ? beta[c] : 0.f;
+  const float rm0 = fin && running_mean ? running_mean[c] : 0.f, rv0 = fin && running_var ? running_var[c] : 0.f;
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) {
     s1 += __shfl_xor(s1, o, 64);
     s2 += __shfl_xor(s2, o, 64);
   }
-  if (r != 0 || c >= C) return;
+  if (!fin) return;
   double mean, var;
   if (train) {
     mean = s1 / count;
@@ -65,17 +70,17 @@ __global__ __launch_bounds__(256) void k_bn_finalize(int C, int train, const dou
     if (var < 0.0) var = 0.0;
     if (running_mean) {
       const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+      running_mean[c] = (float)((1.0 - momentum) * rm0 + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * rv0 + momentum * unb);
     }
   } else {
-    mean = running_mean[c];
-    var = running_var[c];
+    mean = rm0;
+    var = rv0;
   }
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float sc = gamma[c] * invstd;
+  const float sc = ga * invstd;
   scale[c] = sc;
-  shift[c] = beta[c] - (float)mean * sc;
+  shift[c] = be - (float)mean * sc;
   if (save_mean) save_mean[c] = (float)mean;
   if (save_invstd) save_invstd[c] = invstd;
 }
@@ -438,17 +443,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_coeffs(int C, const double* __re
     sg = sums[(size_t)q * 2 * C + c];
     sgz = sums[(size_t)q * 2 * C + C + c];
   }
+  const bool fin = q == 0 && c < C;           // its operands travel beside the sums (see k_bn_finalize)
+  const double mu = fin ? save_mean[c] : 0.f, r = fin ? save_invstd[c] : 0.f, ga = fin ? gamma[c] : 0.f;
+  const float dg0 = fin ? dgamma[c] : 0.f, db0 = fin ? dbeta[c] : 0.f;
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) {
     sg += __shfl_xor(sg, o, 64);
     sgz += __shfl_xor(sgz, o, 64);
   }
-  if (q != 0 || c >= C) return;
-  const double mu = save_mean[c], r = save_invstd[c], ga = gamma[c];
+  if (!fin) return;
   const double dg = r * (sgz - mu * sg);     // sum g * xhat
   const double db = sg;
-  dgamma[c] += (float)dg;
-  dbeta[c] += (float)db;
+  dgamma[c] = dg0 + (float)dg;
+  dbeta[c] = db0 + (float)db;
   const double a = ga * r;
   const double b = -ga * r * r * dg / count;
   const double cc = -a * db / count - b * mu;

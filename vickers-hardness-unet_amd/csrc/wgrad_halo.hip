@@ -19,6 +19,15 @@
 
 #include "vk_common.h"
 
+// -DVK_WH_PIPE=1: the fragment reads of the 2x2-wave 16-bit tiles software-pipelined two (step, tap) units ahead (compute_tile_pipe) —
+// built, bit-identical, 174 tests green, and measured 2-3 % SLOWER than the per-step form in same-box A/B runs through VK_LIB
+// (profiles/r03/wgrad_pipe_experiment.log: 64x64 tap-split kernel 1.839 -> 1.902 ms per step): the partner wave already covers the
+// LDS latency the compiler's schedule exposes; what bounds this kernel is the LDS pipe itself (1.2 transposed reads per MFMA + the
+// staging writes: ~87 % of its cycles).  Default 0 = the per-step form.  Compile-time: both forms in one kernel cost 48 registers.
+#ifndef VK_WH_PIPE
+#define VK_WH_PIPE 0
+#endif
+
 namespace vk {
 
 struct WhSrc {
@@ -275,6 +284,67 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
     }
   };
 
+  // ---- the same four 32-pixel steps as ONE software pipeline over (step, tap) units (16-bit, 2x2 wave layout, stride 1):
+  // the transposed fragment reads of unit u + 2 are issued in front of the MFMAs of unit u, so every read has two units (8 MFMAs,
+  // >= 128 matrix cycles) to return — the per-step form leaves the compiler to place them, and it waits lgkmcnt(1..3) one or two
+  // MFMAs after issuing them (ISA of r02: the LDS latency shows at every tap).  Three V fragment sets, two dz fragment sets;
+  // same accumulation order per accumulator (steps 0..3), so the results are bit-identical.
+  auto compute_tile_pipe = [&](const char* Zs, const char* Vs, auto hsel_c) {
+    constexpr int HSEL = decltype(hsel_c)::value;
+    constexpr int TAP0 = HSEL == 2 ? 5 : 0;
+    constexpr int NTP = HSEL == 0 ? 9 : (HSEL == 1 ? 5 : 4);
+    constexpr int U = 4 * NTP;
+    const char* const Zl = Zs + lane_z;
+    const char* const Vl = Vs + lane_v;
+    u32x4_t zf[2][TK], vf[3][TCc];
+    auto tr = [](const char* q) {
+      const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q));
+      return __builtin_bit_cast(u32x2_t, v);
+    };
+    auto load_unit = [&](auto u_c) {
+      constexpr int u = decltype(u_c)::value;
+      constexpr int ks = u / NTP, tap = TAP0 + u % NTP, r = tap / 3, sx = tap % 3;
+      if constexpr (u % NTP == 0) {
+#pragma unroll
+        for (int a = 0; a < TK; ++a) {
+          const char* b0 = Zl + (32 * ks) * ZSB + (a * 16) * 2;
+          const u32x2_t lo = tr(b0), hi = tr(b0 + 16 * ZSB);
+          zf[ks & 1][a] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < TCc; ++b) {
+        const char* b0 = Vl + ((2 * ks + r) * 18 + sx) * VSB + (b * 16) * 2;
+        const u32x2_t lo = tr(b0), hi = tr(b0 + HRS * VSB);
+        vf[u % 3][b] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+      }
+    };
+    auto mma_unit = [&](auto u_c) {
+      constexpr int u = decltype(u_c)::value;
+      constexpr int ks = u / NTP, t = u % NTP;
+#pragma unroll
+      for (int a = 0; a < TK; ++a)
+#pragma unroll
+        for (int b = 0; b < TCc; ++b) acc[t][a][b] = Mma<T>::run(zf[ks & 1][a], vf[u % 3][b], acc[t][a][b]);
+    };
+    auto unit = [&](auto u_c, auto&& self) {
+      constexpr int u = decltype(u_c)::value;
+      if constexpr (u < U) {
+        if constexpr (u + 2 < U) {
+          load_unit(std::integral_constant<int, u + 2>{});
+          __builtin_amdgcn_sched_group_barrier(0x100, ((u + 2) % NTP == 0 ? 2 * TK : 0) + 2 * TCc, 0);
+        }
+        mma_unit(u_c);
+        __builtin_amdgcn_sched_group_barrier(0x008, TK * TCc, 0);
+        self(std::integral_constant<int, u + 1>{}, self);
+      }
+    };
+    load_unit(std::integral_constant<int, 0>{});
+    load_unit(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * TK + 4 * TCc, 0);
+    unit(std::integral_constant<int, 0>{}, unit);
+  };
+
   // ---- stream over this workgroup's pixel tiles: t = blockIdx.z, + splits, ...
   const int dbg = p.dbg_skip_epilogue >> 1;     // timing experiments (VK_WH_DBG, results WRONG): 1 no tile loads, 2 no LDS tile stores, 4 no MFMA steps, 8 no barriers
   int t = blockIdx.z;
@@ -300,11 +370,15 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
         } else {
           // the next tile's LDS writes (other stage buffer) go between the 32-pixel steps instead of after the last one: the
           // ds_write_b128 transfers then run beside the MFMAs of the remaining steps instead of in front of the barrier
-          compute_step(Zs, Vs, 0, hsel_c);
-          compute_step(Zs, Vs, 1, hsel_c);
-          if (STORE_MID && more && !(dbg & 2)) { store_tile((it + 1) & 1, zs, vs, ms); stored = true; }
-          compute_step(Zs, Vs, 2, hsel_c);
-          compute_step(Zs, Vs, 3, hsel_c);
+          if constexpr (VK_WH_PIPE && EB == 2 && STR == 1) {
+            compute_tile_pipe(Zs, Vs, hsel_c);
+          } else {
+            compute_step(Zs, Vs, 0, hsel_c);
+            compute_step(Zs, Vs, 1, hsel_c);
+            if (STORE_MID && more && !(dbg & 2)) { store_tile((it + 1) & 1, zs, vs, ms); stored = true; }
+            compute_step(Zs, Vs, 2, hsel_c);
+            compute_step(Zs, Vs, 3, hsel_c);
+          }
         }
       }
       if (!stored && more && !(dbg & 2)) store_tile((it + 1) & 1, zs, vs, ms);
