@@ -101,7 +101,10 @@ def main():
                 res = {x: [] for x in vals}
                 for rnd_ in range(a.rounds + 1):
                     for x in vals:
-                        os.environ[var] = x
+                        if x == "":
+                            os.environ.pop(var, None)
+                        else:
+                            os.environ[var] = x
                         for _ in range(2):
                             L_.check(f())
                         torch.cuda.synchronize()

@@ -1946,6 +1946,322 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const HaloParams p) {
   halo_epilogue<T, TH, BN, TP, TC>(smem, acc, p, n, y0, x0, n0, wrow0, 0);
 }
 
+// ---- streaming form for the small-channel layers of decoder blocks 3 / 4 (r03): C_in = 16 or 32 (one source, optionally nearest-x2
+// upsampled), K = 16 or 32, 16-bit types, stride 1 — forward with BatchNorm statistics, data gradient with the fused BN+ReLU-backward
+// reduce and / or the 2x2 pooling (upsample backward).  These layers move 0.4-0.8 GB per launch for a few GFLOP: HBM-bound, and the
+// tile kernels run them at 25-40 % of the HBM peak — every 16x16 tile is a load -> barrier -> MFMAs -> barrier -> LDS transposition
+// -> store -> 32 fp64 atomics chain, and the only latency hiding is having 3-5 such workgroups per CU.
+// Here every WAVE is its own pipeline and there is no workgroup barrier at all:
+//   * a wave owns a strip of 16 output columns x RS rows and walks down it; per output row it needs ONE new input row
+//     (18 pixels = 36 / 72 sixteen-byte vectors; the rows above are still in its private LDS ring): each input pixel is fetched
+//     once per strip (+ 2 / 16 halo columns), BN+ReLU-transformed once, written to LDS once;
+//   * the next three input rows are always in flight in registers (a shift-register queue), so the HBM round trip is covered by
+//     the wave's own look-ahead instead of by neighbours;
+//   * the filter (<= 9 x 32 x 32) lives in registers for the whole strip; fragment reads are ds_read_b128 from the ring with the
+//     conflict-free 48 / 96-byte pixel stride of the tile kernels; 5 (C = 16: two taps per K = 32 step) or 9 MFMAs per row and
+//     16-channel tile;
+//   * output rows leave straight from the accumulators (lane = 4 consecutive channels of one pixel: 8-byte stores, 512 contiguous
+//     bytes per row for K = 16); BatchNorm sums stay in registers for the whole strip and become 16 fp64 atomics per wave at its end.
+// Arithmetic per output element is the same as in the tile kernels (same MFMA operand order per accumulator: taps in ascending
+// order, one chunk), statistics are over the stored (rounded) values, pooling adds the four rounded values in the tile kernels' order.
+template <typename T, int CIN, bool UP>
+struct StreamCfg {
+  static constexpr int NSTEP = CIN == 16 ? 5 : 9;
+  static constexpr int APS = CIN == 16 ? 48 : 96;          // LDS pixel stride (conflict-free fragment reads, as C16Cfg / ColCfg)
+  static constexpr int NPX = UP ? 10 : 18;                 // staged source pixels per row
+  static constexpr int VPP = CIN / 8;                      // 16-byte vectors per pixel
+  static constexpr int NVEC = NPX * VPP;                   // vectors per staged row
+  static constexpr int NLD = (NVEC + 63) / 64;             // loads per lane and row
+  static constexpr int ROWB = CIN == 16 ? 1024 : 2048;     // ring slot
+  static constexpr int RING = 4, DEPTH = 3;
+  static constexpr int ZERO_OFF = RING * ROWB;
+  static constexpr int WAVE_LDS = RING * ROWB + 64;        // + a zero line (the non-existent 10th tap at C = 16)
+  static constexpr int SMEM = 4 * WAVE_LDS;
+  static constexpr int RS = 32;                            // output rows per strip (even: 2x2 pooling pairs rows)
+  static_assert(NPX * APS <= ROWB && NLD <= 2, "row image");
+};
+
+// MODE: 0 forward (operand transform, optional BatchNorm statistics), 2 data gradient + fused BN+ReLU-backward reduce of the layer
+// below, 3 the same behind the 2x2 pooling (upsample backward).  Compile-time, so that the row loop is straight-line code per phase and
+// the compiler can count which vector-memory operations are still in flight (runtime branches made it wait vmcnt(0) per row).
+template <typename T, int CIN, int TC, bool UP, int MODE>
+__global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p) {
+  using Cfg = StreamCfg<T, CIN, UP>;
+  constexpr int NSTEP = Cfg::NSTEP, APS = Cfg::APS, VPP = Cfg::VPP, NVEC = Cfg::NVEC, NLD = Cfg::NLD, ROWB = Cfg::ROWB;
+  constexpr int RS = Cfg::RS, VE = 8;
+  constexpr bool BNR = MODE >= 2, POOL = MODE == 3;
+  static_assert(sizeof(T) == 2, "16-bit element types");
+  static_assert(!(UP && MODE != 0), "the upsampled source occurs in forward launches only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* const ring = smem + wave * Cfg::WAVE_LDS;
+  const int strips_x = (p.W + 15) / 16, strips_y = (p.H + RS - 1) / RS;
+  int sid = (int)blockIdx.x * 4 + wave;
+  if (sid >= p.N * strips_y * strips_x) return;               // no workgroup barrier anywhere below: waves are independent
+  const int strip = sid;
+  const int sx = sid % strips_x;
+  sid /= strips_x;
+  const int sy = sid % strips_y;
+  const int n = sid / strips_y;
+  const int x0 = sx * 16, ys = sy * RS, ye = min(p.H, ys + RS);
+  const int li = lane & 15, kg = lane >> 4;
+  const int Hs = p.H >> (UP ? 1 : 0), Ws = p.W >> (UP ? 1 : 0);
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.s0.ptr, p.s0.bytes);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
+
+  // ---- the filter: registers, for the whole strip.  C = 16: plain [K][9][16] weights, step = taps (2 step, 2 step + 1);
+  // C = 32: halo pack [9][K][4 swizzled 16-byte pieces], step = tap
+  u32x4_t wf[NSTEP][TC];
+#pragma unroll
+  for (int st = 0; st < NSTEP; ++st)
+#pragma unroll
+    for (int a = 0; a < TC; ++a) {
+      const int row = a * 16 + li;
+      uint32_t off;
+      bool ok = row < p.K;
+      if (CIN == 16) {
+        const int tap = 2 * st + (kg >> 1);
+        ok = ok && tap < 9;
+        const int tp = p.flip ? 8 - tap : tap;
+        off = (uint32_t)(((row * 9 + tp) * 16 + (kg & 1) * VE) * 2);
+      } else {
+        const int tp = p.flip ? 8 - st : st;
+        const int pos = kg ^ (((row >> 2) & 1) << 1);
+        off = (uint32_t)(((tp * p.K + row) * 4 + pos) * 16);
+      }
+      wf[st][a] = buf_load16(rsw, ok ? off : kOOB);
+    }
+  if (lane < 4) *reinterpret_cast<u32x4_t*>(ring + Cfg::ZERO_OFF + lane * 16) = u32x4_t{0, 0, 0, 0};
+
+  // ---- staging geometry of this lane (fixed for the strip): vector v -> source pixel hx, 16-byte piece hv
+  const bool aff = MODE == 0 && p.s0.scale != nullptr, relu = p.s0.relu != 0;
+  int st_off[NLD], ld_col[NLD];
+  bool xok[NLD];
+  float sc[VE], sh[VE];
+#pragma unroll
+  for (int q = 0; q < NLD; ++q) {
+    const int v = lane + 64 * q;
+    const int hx = v / VPP, hv = v % VPP;
+    const int xs = (UP ? (x0 >> 1) : x0) - 1 + hx;
+    xok[q] = v < NVEC && (unsigned)xs < (unsigned)Ws;
+    ld_col[q] = xs * CIN + hv * VE;
+    st_off[q] = v < NVEC ? hx * APS + hv * 16 : -1;
+  }
+  if (MODE == 0) {
+    const int hv = lane % VPP;                       // 64 % VPP == 0: both vectors of a lane cover the same channels
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+      sc[j] = aff ? p.s0.scale[hv * VE + j] : 1.f;
+      sh[j] = aff ? p.s0.shift[hv * VE + j] : 0.f;
+    }
+  }
+  auto issue = [&](int j, u32x4_t (&r)[NLD]) {      // request source row j (zeros outside the map)
+    const bool rok = (unsigned)j < (unsigned)Hs;
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const uint32_t off = (uint32_t)(((n * Hs + j) * Ws) * CIN + ld_col[q]) * 2u;
+      r[q] = buf_load16(rs0, (rok && xok[q]) ? off : kOOB);
+    }
+  };
+  auto write_row = [&](int j, const u32x4_t (&r)[NLD]) {
+    const bool rok = (unsigned)j < (unsigned)Hs;
+    char* const slot = ring + (j & 3) * ROWB;
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      if (st_off[q] < 0) continue;
+      u32x4_t v = r[q];
+      if (MODE == 0) {
+        if (aff) v = AffineRelu<T>::run(v, sc, sh, relu);
+        if (!(rok && xok[q])) v = u32x4_t{0, 0, 0, 0};     // zero padding applies AFTER the transform
+      }
+      *reinterpret_cast<u32x4_t*>(slot + st_off[q]) = v;
+    }
+  };
+
+  // ---- fragment-read geometry: step -> (filter row r, column s); C = 16: per lane (two taps per step), C = 32: per step
+  int fr_r16[CIN == 16 ? NSTEP : 1], fr_off16[CIN == 16 ? NSTEP : 1];
+  if (CIN == 16) {
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      const int tap = 2 * st + (kg >> 1);
+      const int r = tap / 3, sxx = tap - r * 3;
+      fr_r16[st] = tap < 9 ? r : -100;
+      fr_off16[st] = (li + sxx) * APS + (kg & 1) * 16;
+    }
+  }
+  const int fr_base32 = kg * 16;                          // + pixel * APS, pixel = li + s or (li + s + 1) >> 1
+
+  // ---- output side
+  const int ld = p.ld0;
+  const bool want_sums = p.stats != nullptr || p.bnr_sums != nullptr;
+  const int xo = x0 + li;
+  const bool x_ok = xo < p.W;
+  float bsc[TC][4], bsh[TC][4], s1[TC][4], s2[TC][4], prev[TC][4];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = a * 16 + kg * 4 + e;
+      bsc[a][e] = BNR && ch < ld ? p.bnr_scale[ch] : 0.f;
+      bsh[a][e] = BNR && ch < ld ? p.bnr_shift[ch] : 0.f;
+      s1[a][e] = 0.f; s2[a][e] = 0.f; prev[a][e] = 0.f;
+    }
+  const int Hh = p.H >> 1, Wh = p.W >> 1;
+  auto round_t = [&](float (&f)[4]) {              // to T and back: everything downstream sees the stored values
+    float g[8] = {f[0], f[1], f[2], f[3], 0.f, 0.f, 0.f, 0.f};
+    const u32x4_t pk = Vec16<T>::pack(g);
+    Vec16<T>::unpack(pk, g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = g[e];
+    return u32x2_t{pk[0], pk[1]};
+  };
+  // element offset of this lane's 4 channels (tile a) at output row y (pooled modes: the half-resolution pixel)
+  auto out_off = [&](int a, int y) -> size_t {
+    const int ch = a * 16 + kg * 4;
+    if (POOL) return (((size_t)n * Hh + (y >> 1)) * Wh + (xo >> 1)) * ld + ch;
+    return (((size_t)n * p.H + y) * p.W + xo) * ld + ch;
+  };
+  // the z vectors of the fused BN+ReLU-backward reduce are requested one output row (pooled: one row pair) ahead
+  u32x2_t zq[2][TC];
+  auto z_issue = [&](int y, u32x2_t (&z)[TC]) {
+    const bool ok = x_ok && y < p.H && (!POOL || (li & 1) == 0);
+#pragma unroll
+    for (int a = 0; a < TC; ++a) {
+      z[a] = u32x2_t{0u, 0u};
+      if (ok && a * 16 + kg * 4 < ld) z[a] = *reinterpret_cast<const u32x2_t*>((const char*)p.bnr_z + out_off(a, y) * 2);
+    }
+  };
+  // masks with the BN+ReLU of the layer below, adds the sums, stores 4 channels of one pixel at element offset eoff
+  auto finish = [&](int a, float (&f)[4], u32x2_t pk, size_t eoff, u32x2_t zr) {
+    if (BNR) {
+      float zf[8];
+      Vec16<T>::unpack(u32x4_t{zr[0], zr[1], 0u, 0u}, zf);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!(fmaf(zf[e], bsc[a][e], bsh[a][e]) > 0.f)) f[e] = 0.f;
+        s1[a][e] += f[e];
+        s2[a][e] += f[e] * zf[e];
+      }
+      pk = round_t(f);
+    } else if (want_sums) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[a][e] += f[e]; s2[a][e] += f[e] * f[e]; }
+    }
+    *reinterpret_cast<u32x2_t*>((char*)p.y0 + eoff * 2) = pk;
+  };
+
+  // ---- the row pipeline.  Source row j lives in queue register set j & 3 until it is written to ring slot j & 3; the loop is
+  // unrolled over the phase of y so that every set index is a compile-time constant (a shift-register queue would MOVE registers
+  // that are the destination of loads in flight, i.e. wait for them: measured, 1.4 us per row).  Look-ahead: three source rows.
+  u32x4_t pre[4][NLD];
+  const int jb = UP ? (ys >> 1) : ys;                      // ys is a multiple of RS = 32, so jb & 3 == 0
+  issue(jb - 1, pre[3]);
+  issue(jb, pre[0]);
+  issue(jb + 1, pre[1]);
+  issue(jb + 2, pre[2]);
+  if (BNR) z_issue(POOL ? ys + 1 : ys, zq[0]);
+  write_row(jb - 1, pre[3]);
+  issue(jb + 3, pre[3]);
+  write_row(jb, pre[0]);
+  // one output row; PH = (y - ys) mod UF, compile-time.  Rows at or beyond H inside the last group are computed on zero rows and
+  // not stored (lane predicate, no branch).
+  auto row = [&](int y, auto ph_c) {
+    constexpr int PH = decltype(ph_c)::value;
+    // the source row this output row newly needs: non-UP: y + 1 every row; UP: (y + 1) >> 1 on odd rows
+    if constexpr (!UP) {
+      constexpr int S = (PH + 1) & 3;                      // slot of row y + 1
+      write_row(y + 1, pre[S]);
+      issue(y + 4, pre[PH & 3]);                           // row y + 4 shares the slot of row y, written one iteration ago
+    } else if constexpr ((PH & 1) == 1) {
+      constexpr int M1 = ((PH + 1) >> 1) & 3;              // slot of source row m + 1 = (y + 1) >> 1
+      const int m1 = (y + 1) >> 1;
+      write_row(m1, pre[M1]);
+      issue(m1 + 3, pre[(M1 + 3) & 3]);
+    }
+    // next row's (row pair's) z vectors
+    constexpr int ZC = POOL ? ((PH >> 1) & 1) : (PH & 1);  // set holding THIS row's z
+    if constexpr (BNR && (!POOL || (PH & 1) == 1)) z_issue(POOL ? y + 2 : y + 1, zq[ZC ^ 1]);
+    f32x4_t acc[TC];
+#pragma unroll
+    for (int a = 0; a < TC; ++a) acc[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      int addr;
+      if (CIN == 16) {
+        const int vrow = y - 1 + fr_r16[st];
+        addr = fr_r16[st] < 0 ? Cfg::ZERO_OFF : (vrow & 3) * ROWB + fr_off16[st];
+      } else {
+        const int r = st / 3, sxx = st - r * 3;
+        const int vrow = y - 1 + r;
+        const int jr = UP ? (vrow >> 1) : vrow;
+        const int pix = UP ? ((li + sxx + 1) >> 1) : (li + sxx);
+        addr = (jr & 3) * ROWB + pix * APS + fr_base32;
+      }
+      const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(ring + addr);
+#pragma unroll
+      for (int a = 0; a < TC; ++a) acc[a] = Mma<T>::run(wf[st][a], xf, acc[a]);
+    }
+    const bool y_ok = y < p.H;
+#pragma unroll
+    for (int a = 0; a < TC; ++a) {
+      const int ch = a * 16 + kg * 4;
+      float f[4] = {acc[a][0], acc[a][1], acc[a][2], acc[a][3]};
+      u32x2_t pk = round_t(f);
+      if constexpr (POOL) {
+        // rows pair up inside the strip (ys and RS are even); the four ROUNDED values are added in the tile kernels' order:
+        // (row 2q, col 2c), (2q, 2c + 1), (2q + 1, 2c), (2q + 1, 2c + 1)
+        if constexpr ((PH & 1) == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) prev[a][e] = f[e];
+        } else {
+          float t[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pn = dpp_f<0xB1>(prev[a][e]), cn = dpp_f<0xB1>(f[e]);      // the odd neighbour column
+            t[e] = ((prev[a][e] + pn) + f[e]) + cn;
+          }
+          if ((li & 1) == 0 && x_ok && y_ok && ch < ld) {
+            const u32x2_t pk2 = round_t(t);
+            finish(a, t, pk2, out_off(a, y), zq[ZC][a]);
+          }
+        }
+      } else if (x_ok && y_ok && ch < ld) {
+        finish(a, f, pk, out_off(a, y), zq[ZC][a]);
+      }
+    }
+  };
+  constexpr int UF = UP ? 8 : 4;
+  for (int yb = ys; yb < ye; yb += UF) {
+    row(yb, std::integral_constant<int, 0>{});
+    row(yb + 1, std::integral_constant<int, 1>{});
+    row(yb + 2, std::integral_constant<int, 2>{});
+    row(yb + 3, std::integral_constant<int, 3>{});
+    if constexpr (UP) {
+      row(yb + 4, std::integral_constant<int, 4>{});
+      row(yb + 5, std::integral_constant<int, 5>{});
+      row(yb + 6, std::integral_constant<int, 6>{});
+      row(yb + 7, std::integral_constant<int, 7>{});
+    }
+  }
+
+  // ---- BatchNorm sums of the strip: 16 lanes of a row hold the same channels -> DPP row sum, one lane per row adds them
+  if (want_sums) {
+    double* const sp = (p.bnr_sums ? p.bnr_sums : p.stats) + (size_t)(strip % VK_STATS_REPLICAS) * 2 * ld;
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = row16_sum(s1[a][e]), v = row16_sum(s2[a][e]);
+        const int ch = a * 16 + kg * 4 + e;
+        if (li == 0 && ch < ld) {
+          atomicAdd(sp + ch, (double)u);
+          atomicAdd(sp + ld + ch, (double)v);
+        }
+      }
+  }
+}
+
 // ---- weight repack into the halo layout.  src: [rows][9][red] of T (rows = output channels of the GEMM: K for forward
 // weights [K][3][3][C], C for the transposed data-gradient weights [C][3][3][K]; red = reduction channels).
 // dst: [red / CK][9][rows][CK] with the four 16-byte pieces of every 64-byte row stored at piece ^ (((row >> 2) & 1) << 1).
@@ -2249,6 +2565,42 @@ static int launch_s2dg(HaloParams p, hipStream_t st) {
   return VK_OK;
 }
 
+template <typename T, int CIN, int TC, bool UP, int MODE>
+static int launch_stream(const HaloParams& p, hipStream_t st) {
+  using Cfg = StreamCfg<T, CIN, UP>;
+  const long strips = (long)p.N * ((p.H + Cfg::RS - 1) / Cfg::RS) * ((p.W + 15) / 16);
+  dim3 grid((unsigned)((strips + 3) / 4), 1, 1);
+  static const std::string tag_f = std::string("stream_16b_c") + std::to_string(CIN) + (UP ? "up" : "") + "_k" + std::to_string(TC * 16);
+  static const std::string tag_d = tag_f + "_dgrad";
+  const std::string& tag = p.flip ? tag_d : tag_f;
+  const double in_px = (double)p.N * (p.H >> (UP ? 1 : 0)) * (p.W >> (UP ? 1 : 0));
+  const double out_px = (double)p.N * p.H * p.W * (p.pool2 ? 0.25 : 1.0);
+  const double bytes = (in_px * CIN + out_px * p.K * (p.bnr_z ? 2.0 : 1.0) + 9.0 * p.K * CIN) * 2.0;
+  vkh::ProfScope ps(tag.c_str(), st, 2.0 * (double)p.N * p.H * p.W * p.K * 9.0 * CIN, bytes);
+  hipLaunchKernelGGL((conv3x3_stream_kernel<T, CIN, TC, UP, MODE>), grid, dim3(256), Cfg::SMEM, st, p);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+// the streaming kernel is instantiated for the launches of decoder blocks 3 / 4 that it is faster on (one source, K in one part, no
+// accumulate); everything else stays on the tile kernels.  VK_NO_STREAM=1 (tests / A-B): tile kernels only;
+// VK_STREAM_ALL=1: every instantiated combination, also where the tile kernels measured faster
+template <typename T>
+static int stream_try(const HaloParams& p, hipStream_t st) {
+  if (getenv("VK_NO_STREAM")) return VK_ERR_UNSUPPORTED;
+  if (p.s1.ptr || p.accumulate || p.split || p.ld0 != p.K) return VK_ERR_UNSUPPORTED;
+  const bool up = p.s0.up != 0, bnr = p.bnr_z != nullptr, pool = p.pool2 != 0;
+  if ((pool || up) && ((p.H | p.W) & 1)) return VK_ERR_UNSUPPORTED;
+  const bool fwd = !p.flip && !bnr && !pool;                                     // forward launch (with or without statistics)
+  if (fwd && p.C == 32 && up && p.K == 16) return launch_stream<T, 32, 1, true, 0>(p, st);        // dec4.conv1
+  if (fwd && p.C == 16 && !up && p.K == 16) return launch_stream<T, 16, 1, false, 0>(p, st);      // dec4.conv2
+  if (fwd && p.C == 32 && !up && p.K == 32) return launch_stream<T, 32, 2, false, 0>(p, st);      // dec3.conv2
+  if (p.flip && !p.s0.scale && bnr && !pool && p.C == 16 && p.K == 16) return launch_stream<T, 16, 1, false, 2>(p, st);   // d(dec4.conv2)
+  if (p.flip && !p.s0.scale && bnr && !pool && p.C == 32 && p.K == 32) return launch_stream<T, 32, 2, false, 2>(p, st);   // d(dec3.conv2)
+  if (p.flip && !p.s0.scale && bnr && pool && p.C == 16 && p.K == 32) return launch_stream<T, 16, 2, false, 3>(p, st);    // d(dec4.conv1)
+  return VK_ERR_UNSUPPORTED;
+}
+
 // returns VK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the tap-by-tap kernel)
 // w: halo pack (vk_halo_pack) when `packed`, plain [K][3][3][C] otherwise — only the C == 16 kernel takes the plain layout
 int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, void* y1, int split_k1, int accumulate, double* stats,
@@ -2308,6 +2660,10 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, 
   p.bnr_shift = bnr ? bnr->shift : nullptr;
   p.bnr_sums = bnr ? bnr->sums : nullptr;
   p.nchunks = c16 ? 1 : C / ck;
+  if (eb == 2 && !s2 && !s2d && (c16 || C == 32)) {      // small-channel decoder layers: the streaming kernel where it covers the launch
+    const int rc = d->dtype == VK_BF16 ? stream_try<bf16_t>(p, st) : stream_try<f16_t>(p, st);
+    if (rc != VK_ERR_UNSUPPORTED) return rc;
+  }
   if (c16) {
     if (d->dtype == VK_BF16) return d->K >= 32 ? launch_c16<bf16_t, 32>(p, st) : launch_c16<bf16_t, 16>(p, st);
     return d->K >= 32 ? launch_c16<f16_t, 32>(p, st) : launch_c16<f16_t, 16>(p, st);
