@@ -19,6 +19,14 @@ def family(name):
     if m:
         t, th, bn, wm, wn = m.groups()
         return f"colq_{'f32' if t == 'float' else '16b'}_t{th}_bn{bn}_w{int(wm) * int(wn)}"
+    m = re.search(r"conv3x3_cols_kernel<vk::(\w+), (\d+), (\d+), (\d+), (\d+)>", name)      # the staggered form (opt-in)
+    if m:
+        t, th, bn, wm, wn = m.groups()
+        return f"cols_{'f32' if t == 'float' else '16b'}_t{th}_bn{bn}_w{int(wm) * int(wn)}"
+    m = re.search(r"conv3x3_stream_kernel<vk::(\w+), (\d+), (\d+), (\w+), (\d+)>", name)    # streaming small-channel kernel (fwd + dgrad share a symbol per mode)
+    if m:
+        t, cin, tc, up, mode = m.groups()
+        return f"stream_16b_c{cin}{'up' if up == 'true' else ''}_k{int(tc) * 16}" + ("_dgrad" if mode != "0" else "")
     m = re.search(r"conv3x3_colp_kernel<vk::(\w+), (\d+), (\d+), (\d+), (\d+)", name)      # the persistent form runs under the plain tag
     if m:
         t, th, bn, wm, wn = m.groups()
