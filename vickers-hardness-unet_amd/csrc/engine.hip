@@ -240,8 +240,14 @@ __global__ __launch_bounds__(256) void k_pack_halo_tab(const HaloPackEntry* __re
     const int r0 = cc * CK + j * VE;
     float f[VE];
     if (!e.transposed) {
+      // VE consecutive reduction channels: whole 16-byte vectors (parameter offsets are multiples of 4 floats, red and r0 of VE)
+      const f32x4_t* s4 = reinterpret_cast<const f32x4_t*>(src + ((long)k * 9 + tap) * red + r0);
 #pragma unroll
-      for (int i = 0; i < VE; ++i) f[i] = src[((long)k * 9 + tap) * red + r0 + i];
+      for (int q = 0; q < VE / 4; ++q) {
+        const f32x4_t t = s4[q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[4 * q + i] = t[i];
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < VE; ++i) f[i] = src[((long)(r0 + i) * 9 + tap) * rows + k];
@@ -253,6 +259,18 @@ __global__ __launch_bounds__(256) void k_pack_halo_tab(const HaloPackEntry* __re
 template <typename T>
 __global__ void k_cast_flat(size_t n, const float* __restrict__ src, T* __restrict__ dst) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st1(dst + i, src[i]);
+}
+
+// 16-bit working copy of the layers that read PLAIN weights (1x1 shortcuts, the C = 16 layer): the ranges of the flat buffer they
+// occupy — 0.17 M of the 24.4 M parameters; every other layer reads a halo / stem / data-gradient pack built straight from fp32
+struct CastRange {
+  int64_t begin, count;
+};
+template <typename T>
+__global__ void k_cast_ranges(const CastRange* __restrict__ tab, const float* __restrict__ src, T* __restrict__ dst) {
+  const CastRange r = tab[blockIdx.y];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < r.count; i += (int64_t)gridDim.x * blockDim.x)
+    st1(dst + r.begin + i, src[r.begin + i]);
 }
 
 // stem pack: wp[k][r][s*4 + c] = w[k][r][s][c] (s < 7, c < 3), zero elsewhere;  w is KRSC [64][7][7][3]
@@ -380,6 +398,8 @@ struct vk_unet {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_dirty = false;
   std::vector<PackEntry> pack_tab;
+  std::vector<CastRange> cast_tab;
+  size_t off_tab_cast = 0;
   std::vector<BnEvalEntry> bn_tab;
   std::map<std::string, std::pair<void*, std::vector<int>>> debug;
 
@@ -589,6 +609,7 @@ void layout_workspace(vk_unet* h) {
   h->splitk_bytes = (!tr && (size_t)N * S * S <= 4u * 512 * 512) ? VK_SPLITK_WORKSPACE_BYTES : 0;
   h->off_splitk = h->splitk_bytes ? take(h->splitk_bytes) : 0;
   h->off_tab_pack = take(h->convs.size() * sizeof(PackEntry));
+  h->off_tab_cast = take(h->convs.size() * sizeof(CastRange));
   h->off_tab_bn = take(h->bns.size() * sizeof(BnEvalEntry));
   h->ws_bytes = off;
 }
@@ -827,6 +848,12 @@ extern "C" int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_b
     e.src = c.w_off; e.dst = c.wd_off; e.K = c.K; e.RS = c.R * c.R; e.C = c.Cin; e.pad_ = 0;
     h->pack_tab.push_back(e);
   }
+  h->cast_tab.clear();
+  for (size_t i = 0; i < h->convs.size(); ++i) {
+    const ConvL& c = h->convs[i];
+    if ((int)i == h->stem_conv || (int)i == h->head_conv || c.halo_fwd) continue;     // stem: own pack; head: fp32; tile layers: halo pack
+    h->cast_tab.push_back(CastRange{c.w_off, (int64_t)c.K * c.Cin * c.R * c.R});
+  }
   h->bn_tab.clear();
   for (const BnL& b : h->bns) {
     BnEvalEntry e;
@@ -837,6 +864,8 @@ extern "C" int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_b
     VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_pack, h->pack_tab.data(), h->pack_tab.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
   if (!h->halo_tab.empty())
     VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_halo, h->halo_tab.data(), h->halo_tab.size() * sizeof(HaloPackEntry), hipMemcpyHostToDevice));
+  if (!h->cast_tab.empty())
+    VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_cast, h->cast_tab.data(), h->cast_tab.size() * sizeof(CastRange), hipMemcpyHostToDevice));
   VK_CHECK_HIP(hipMemcpy(h->ws + h->off_tab_bn, h->bn_tab.data(), h->bn_tab.size() * sizeof(BnEvalEntry), hipMemcpyHostToDevice));
   if (h->cfg.training && !h->side && getenv("VK_SIDE_STREAM")) RET_IF(vk_unet_set_side_stream(h, 1));
   h->bound = true;
@@ -845,8 +874,10 @@ extern "C" int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_b
 
 template <typename T>
 static int refresh_t(vk_unet* h, hipStream_t st) {
-  if (sizeof(T) != 4)
-    hipLaunchKernelGGL(k_cast_flat<T>, dim3(2048), dim3(256), 0, st, (size_t)h->n_params, h->params, (T*)(h->ws + h->off_wf));
+  vkh::ProfScope ps_("weights_repack", st, 0.0, (double)h->n_params * (4.0 + 2.0 * sizeof(T)));
+  if (sizeof(T) != 4 && !h->cast_tab.empty())
+    hipLaunchKernelGGL(k_cast_ranges<T>, dim3(16, (unsigned)h->cast_tab.size()), dim3(256), 0, st, (const CastRange*)(h->ws + h->off_tab_cast),
+                       h->params, (T*)(h->ws + h->off_wf));
   if (h->cfg.training && !h->pack_tab.empty())
     hipLaunchKernelGGL(k_pack_dgrad<T>, dim3(64, (unsigned)h->pack_tab.size()), dim3(256), 0, st,
                        (const PackEntry*)(h->ws + h->off_tab_pack), h->params, (T*)(h->ws + h->off_wd));
