@@ -88,6 +88,7 @@ def main():
         ops = {
             "fwd": lambda: fn_f(C.byref(d_f), wf.data_ptr(), y.data_ptr(), None, 0, 0, None if a.no_stats else stats.data_ptr(), st),
             "dgrad": lambda: fn_d(C.byref(d_d), wd_.data_ptr(), dx.data_ptr(), None, 0, 0, None, st),
+            "dgrad_acc": lambda: fn_d(C.byref(d_d), wd_.data_ptr(), dx.data_ptr(), None, 0, 1, None, st),
             "dgrad_bnr": lambda: lib.vk_conv_dgrad_fused(C.byref(d_d), wd_.data_ptr(), dx.data_ptr(), None, 0, 0, C.byref(bnr), st),
             "wgrad": lambda: lib.vk_conv_wgrad(C.byref(d_f), dz.data_ptr(), dw.data_ptr(), wsl.data_ptr(), wsl.numel(), st),
         }
