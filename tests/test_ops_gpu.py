@@ -787,6 +787,63 @@ def test_head_fwd_bwd(dtn):
     assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
 
 
+@pytest.mark.parametrize("path", ["mfma", "valu"])
+@pytest.mark.parametrize("shape", [(2, 24, 24), (1, 40, 33), (3, 16, 48)], ids=["24", "ragged", "wide"])
+@pytest.mark.parametrize("dtn", ["f32", "bf16", "f16"])
+def test_head_bwd_fused(dtn, shape, path, monkeypatch):
+    """vk_head_bwd_fused = head data gradient masked by relu(bn(z)) > 0 + BN-backward sums + head weight / bias gradient.  16-bit types
+    run ONE matrix-core kernel (k_head_bwd_mfma: dlogits and the filter rounded to the 16-bit type, as autocast does in the reference,
+    train.py:431-438) unless VK_HEAD_NO_MFMA is set; both paths against fp64 autograd of the SAME rounded operands for the MFMA path and
+    of the fp32 operands for the VALU path.  Ragged maps: pixels outside add nothing to any sum."""
+    dt = DT[dtn]
+    if path == "valu":
+        monkeypatch.setenv("VK_HEAD_NO_MFMA", "1")
+    else:
+        monkeypatch.delenv("VK_HEAD_NO_MFMA", raising=False)
+    lowp = path == "mfma" and dt != torch.float32
+    N, H, W = shape
+    z = rnd(gen(N, 16, H, W, seed=221), dt)
+    g = torch.Generator().manual_seed(222)
+    sc, sh = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.3
+    w = gen(1, 16, 3, 3, seed=223, scale=0.2)
+    dl = gen(N, 1, H, W, seed=224)
+    pre = z * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)                       # fp32, as the kernels compute it
+    a_in = rnd(torch.relu(pre), dt) if lowp else torch.relu(pre)                # the MFMA path stages relu(bn(z)) as T
+    a = a_in.double().requires_grad_(True)
+    wv = (rnd(w, dt) if lowp else w).clone().double().requires_grad_(True)
+    out = F.conv2d(a, wv, None, padding=1)
+    out.backward((rnd(dl, dt) if lowp else dl).double())
+    gy = rnd(a.grad.float(), dt) * (pre > 0)                                     # stored gradient: rounded, then masked
+    s1_ref = gy.double().sum(dim=(0, 2, 3))
+    s2_ref = (gy.double() * z.double()).sum(dim=(0, 2, 3))
+    # dW / dbias of the head see the UNMASKED activations: autograd above gives them directly
+    zd = to_nhwc(z, dt)
+    w9 = D(w[0].permute(1, 2, 0).contiguous())
+    scd, shd = D(sc), D(sh)
+    src = mk_src(zd, 16, 0, scd, shd, 1)
+    dld = D(dl)
+    ws = torch.empty(1024 * 148 * 4, dtype=torch.uint8, device=dev())
+    outs = []
+    for rep in range(2):
+        dy = torch.full((N, H, W, 16), 7.0, dtype=dt, device=dev())
+        dw = torch.zeros(3, 3, 16, device=dev())
+        db = torch.zeros(1, device=dev())
+        sums = torch.zeros(REPL * 32, dtype=torch.float64, device=dev())
+        bnr = L_.vk_bnr(zd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sums.data_ptr())
+        vk._lib.check(vk.lib().vk_head_bwd_fused(L_.dtype_code(dt), N, H, W, C.byref(src), w9.data_ptr(), dld.data_ptr(), dy.data_ptr(),
+                                                 dw.data_ptr(), db.data_ptr(), C.byref(bnr), ws.data_ptr(), ws.numel(), st()))
+        torch.cuda.synchronize()
+        got = dy.cpu().permute(0, 3, 1, 2).float()
+        assert (got - gy).abs().max().item() <= tol(dt, gy) + 1e-7      # (MFMA path: same operands, only the accumulation order differs -> at most one rounding step)
+        ss = sums.view(REPL, 2, 16).sum(0).cpu()
+        assert (ss[0] - s1_ref).abs().max().item() <= 2e-2 * gy.abs().max().item() * (N * H * W) ** 0.5 * (1.0 if dt != torch.float32 else 1e-3)
+        assert (ss[1] - s2_ref).abs().max().item() <= 2e-2 * (gy.abs().max() * z.abs().max()).item() * (N * H * W) ** 0.5 * (1.0 if dt != torch.float32 else 1e-3)
+        assert (dw.cpu().permute(2, 0, 1) - wv.grad[0].float()).abs().max().item() <= 1e-3 * wv.grad.abs().max().item()
+        assert abs(db.item() - dl.double().sum().item()) <= 1e-3 * abs(dl.double().sum().item()) + 1e-3
+        outs.append((dy, dw, db, ss))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
 @pytest.mark.parametrize("wb,wd", [(1.0, 1.0), (0.0, 1.0), (1.0, 0.0)])
 def test_bce_dice_loss(wb, wd):
     from oracle import unet_oracle as O

@@ -672,21 +672,24 @@ __global__ __launch_bounds__(256) void k_head_fwd(int N, int H, int W, int tiles
   }
   __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;
-  float acc = bias[0];
+  // two accumulator pairs (channels 4q, 4q+1 / 4q+2, 4q+3) so that the 144 products go through v_pk_fma_f32, two per lane and cycle,
+  // in two independent chains — one scalar chain of 144 dependent FMAs made this kernel VALU-bound at 2.2x its HBM time (r03)
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t acc_a = f32x2_t{bias[0], 0.f}, acc_b = f32x2_t{0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       const float* a = &tile[((ty + r) * 18 + tx + s) * PS];
+      const float* wt = w + (r * 3 + s) * 16;
 #pragma unroll
       for (int j = 0; j < 16; j += 4) {
         const f32x4_t av = *reinterpret_cast<const f32x4_t*>(a + j);
-        acc = fmaf(av[0], w[(r * 3 + s) * 16 + j], acc);
-        acc = fmaf(av[1], w[(r * 3 + s) * 16 + j + 1], acc);
-        acc = fmaf(av[2], w[(r * 3 + s) * 16 + j + 2], acc);
-        acc = fmaf(av[3], w[(r * 3 + s) * 16 + j + 3], acc);
+        acc_a = __builtin_elementwise_fma(f32x2_t{av[0], av[1]}, f32x2_t{wt[j], wt[j + 1]}, acc_a);
+        acc_b = __builtin_elementwise_fma(f32x2_t{av[2], av[3]}, f32x2_t{wt[j + 2], wt[j + 3]}, acc_b);
       }
     }
+  const float acc = (acc_a[0] + acc_a[1]) + (acc_b[0] + acc_b[1]);
   const int y = y0 + ty, x = x0 + tx;
   if (y < H && x < W) logits[((size_t)n * H + y) * W + x] = acc;
 }
@@ -870,6 +873,194 @@ __global__ __launch_bounds__(256) void k_head_wgrad(int N, int H, int W, int til
   for (int j = 0; j < 144; ++j) {
     const float v = wave_sum(gw[j]);
     if (lane == 0) red[wave][j] = v;
+  }
+  {
+    const float v = wave_sum(gb);
+    if (lane == 0) red[wave][144] = v;
+  }
+  __syncthreads();
+  if (tid < 145) {
+    const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (part) part[(size_t)blockIdx.x * 148 + tid] = v;       // reproducible mode: k_head_wgrad_reduce adds the workgroups in order
+    else if (tid < 144) atomicAdd(dw + tid, v);
+    else atomicAdd(dbias, v);
+  }
+}
+
+// ---- backward, data + weights in ONE pass on the matrix cores (16-bit types, r03).  The two kernels above are VALU-bound (144 FMAs
+// per pixel each, the BN+ReLU transform of the same z twice) at 134 + 117 us for 570 + 300 MB; here per 16x16 tile
+//   * every thread stages its pixel once: raw z, a = relu(bn(z)) (AffineRelu, as every other convolution stages its operand) and the
+//     pixel's nine shifted dlogits as a 16-"channel" vector T[px][tap] (taps 9..15 zero), all as T in wave-private LDS tiles
+//     (32 B per pixel; the wave that writes a tile is the only one that reads it: no workgroup barrier for them);
+//   * data gradient: D[c][px] = sum_tap W[c][tap] T[px][tap] — one 16x16x32 MFMA per 16 pixels (A = the head filter as a constant
+//     fragment, B = ds_read_b128 of T), lane = 4 channels of one pixel as in the convolution kernels: round, ReLU mask from z,
+//     BN-backward sums, 8-byte store;
+//   * weight gradient: D[tap][c] += sum_px T[px][tap] a[px][c] — the LDS-transposed fragment reads of wgrad_halo_kernel with T in the
+//     role of dz: one MFMA per 32 pixels, one f32x4 accumulator per wave for the whole launch.
+// dlogits and the filter are rounded to T here (what autocast does to them in the reference: the head convolution runs in the
+// low-precision type, train.py:431-438); accumulation, the gradient of the filter and the sums stay fp32 / fp64.
+template <typename T>
+__global__ __launch_bounds__(256) void k_head_bwd_mfma(int N, int H, int W, int tiles_x, int tiles_y, int ntiles, const T* __restrict__ z,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                       const float* __restrict__ w, const float* __restrict__ dl, T* __restrict__ dy,
+                                                       double* bnr_sums, float* dw, float* dbias, float* __restrict__ part) {
+  static_assert(sizeof(T) == 2, "16-bit element types");
+  constexpr int PXB = 32;                                   // bytes per pixel of the wave-private tiles (16 elements)
+  __shared__ float dt[2][18 * 18];
+  __shared__ __attribute__((aligned(16))) char wl[4][3][64 * PXB];
+  __shared__ float red[4][148];
+  typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ty = tid >> 4, tx = tid & 15;
+  const int li = lane & 15, kg = lane >> 4;
+  char* const zt = wl[wave][0];
+  char* const at = wl[wave][1];
+  char* const Tt = wl[wave][2];
+  float sc[16], sh[16], bsc[4], bsh[4];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { sc[j] = scale[j]; sh[j] = shift[j]; }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { bsc[e] = scale[kg * 4 + e]; bsh[e] = shift[kg * 4 + e]; }
+  // constant A fragment of the data gradient: W[c = li][tap = 8 kg + i], taps >= 9 are zero
+  u32x4_t wfrag;
+  {
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tap = kg * 8 + i;
+      f[i] = tap < 9 ? w[tap * 16 + li] : 0.f;
+    }
+    wfrag = Vec16<T>::pack(f);
+  }
+  f32x4_t dwacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float gb = 0.f, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  // transposed-read lane geometry of wgrad_halo_kernel at a 32-byte pixel stride
+  const int lane_t = (4 * (lane >> 4) + ((lane & 15) >> 2)) * PXB + (4 * (lane & 3)) * 2;
+  auto tr = [](const char* q) { return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q))); };
+
+  u32x4_t ar[2], ar_n[2];
+  float dr[2], dr_n[2];
+  bool ok = false, ok_n = false;
+  auto fetch = [&](int t, u32x4_t (&av)[2], float (&dv)[2], bool& inb) {
+    int bt = t;
+    const int tx0 = bt % tiles_x;
+    bt /= tiles_x;
+    const int ty0 = bt % tiles_y;
+    const int n = bt / tiles_y;
+    const int y0 = ty0 * 16, x0 = tx0 * 16;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int hp = tid + k * 256;
+      const int hy = hp / 18, hx = hp - hy * 18;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      dv[k] = (hp < 324 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? dl[((size_t)n * H + y) * W + x] : 0.f;
+    }
+    const int y = y0 + ty, x = x0 + tx;
+    inb = y < H && x < W;
+    const T* zp = z + (((size_t)n * H + (inb ? y : 0)) * W + (inb ? x : 0)) * 16;
+    av[0] = *reinterpret_cast<const u32x4_t*>(zp);
+    av[1] = *reinterpret_cast<const u32x4_t*>(zp + 8);
+  };
+  int t = blockIdx.x;
+  if (t < ntiles) {
+    fetch(t, ar, dr, ok);
+    dt[0][tid] = dr[0];
+    if (tid + 256 < 324) dt[0][tid + 256] = dr[1];
+  }
+  __syncthreads();
+  for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+    const bool has_next = t + (int)gridDim.x < ntiles;
+    if (has_next) fetch(t + gridDim.x, ar_n, dr_n, ok_n);
+    int bt = t;
+    const int tx0 = bt % tiles_x;
+    bt /= tiles_x;
+    const int ty0 = bt % tiles_y;
+    const int n = bt / tiles_y;
+    const int y0 = ty0 * 16, x0 = tx0 * 16;
+    const float* d = dt[it & 1];
+    // ---- thread = pixel: the three wave-private tiles
+    {
+      const u32x4_t z0 = ok ? ar[0] : u32x4_t{0, 0, 0, 0}, z1 = ok ? ar[1] : u32x4_t{0, 0, 0, 0};
+      *reinterpret_cast<u32x4_t*>(zt + lane * PXB) = z0;
+      *reinterpret_cast<u32x4_t*>(zt + lane * PXB + 16) = z1;
+      u32x4_t a0 = AffineRelu<T>::run(z0, sc, sh, relu != 0), a1 = AffineRelu<T>::run(z1, sc + 8, sh + 8, relu != 0);
+      if (!ok) { a0 = u32x4_t{0, 0, 0, 0}; a1 = u32x4_t{0, 0, 0, 0}; }          // pixels outside the map add nothing to dW
+      *reinterpret_cast<u32x4_t*>(at + lane * PXB) = a0;
+      *reinterpret_cast<u32x4_t*>(at + lane * PXB + 16) = a1;
+      float tf[16];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) tf[r * 3 + s_] = d[(ty + 2 - r) * 18 + tx + 2 - s_];     // halo origin (y0-1, x0-1): pixel + (1-r, 1-s)
+#pragma unroll
+      for (int k = 9; k < 16; ++k) tf[k] = 0.f;
+      *reinterpret_cast<u32x4_t*>(Tt + lane * PXB) = Vec16<T>::pack(tf);
+      *reinterpret_cast<u32x4_t*>(Tt + lane * PXB + 16) = Vec16<T>::pack(tf + 8);
+      gb += d[(ty + 1) * 18 + tx + 1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- weight gradient: two 32-pixel steps
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const char* tq = Tt + lane_t + (32 * ks) * PXB;
+      const char* aq = at + lane_t + (32 * ks) * PXB;
+      const u32x2_t tl = tr(tq), th = tr(tq + 16 * PXB), al = tr(aq), ah = tr(aq + 16 * PXB);
+      dwacc = Mma<T>::run(u32x4_t{tl[0], tl[1], th[0], th[1]}, u32x4_t{al[0], al[1], ah[0], ah[1]}, dwacc);
+    }
+    // ---- data gradient: tile rows 4 wave + j, lane = 4 channels (4 kg ..) of pixel li
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pl = j * 16 + li;
+      u32x4_t X = *reinterpret_cast<const u32x4_t*>(Tt + pl * PXB + (kg & 1) * 16);
+      if (kg >= 2) X = u32x4_t{0, 0, 0, 0};
+      const f32x4_t o = Mma<T>::run(wfrag, X, f32x4_t{0.f, 0.f, 0.f, 0.f});
+      const u32x2_t zr = *reinterpret_cast<const u32x2_t*>(zt + pl * PXB + kg * 8);
+      const int y = y0 + 4 * wave + j, x = x0 + li;
+      const bool okd = y < H && x < W;
+      float f[8] = {o[0], o[1], o[2], o[3], 0.f, 0.f, 0.f, 0.f}, zf[8];
+      u32x4_t pk = Vec16<T>::pack(f);
+      Vec16<T>::unpack(pk, f);                        // sums are over the STORED (rounded) values
+      Vec16<T>::unpack(u32x4_t{zr[0], zr[1], 0u, 0u}, zf);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!okd || !(fmaf(zf[e], bsc[e], bsh[e]) > 0.f)) f[e] = 0.f;
+        s1[e] += f[e];
+        s2[e] += f[e] * zf[e];
+      }
+      pk = Vec16<T>::pack(f);
+      if (okd) *reinterpret_cast<u32x2_t*>(dy + (((size_t)n * H + y) * W + x) * 16 + kg * 4) = u32x2_t{pk[0], pk[1]};
+    }
+    if (has_next) {                  // the other dlogits buffer was last read one iteration ago, before the barrier below
+      float* dn = dt[(it + 1) & 1];
+      dn[tid] = dr_n[0];
+      if (tid + 256 < 324) dn[tid + 256] = dr_n[1];
+      ar[0] = ar_n[0]; ar[1] = ar_n[1];
+      ok = ok_n;
+    }
+    __syncthreads();
+  }
+  // ---- BN-backward sums: [replica][2][16]
+  {
+    float* bred = red[0];                     // [wave][32] inside red (148 floats per wave)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = row16_sum(s1[e]), b = row16_sum(s2[e]);
+      if (li == 0) { red[wave][kg * 4 + e] = a; red[wave][16 + kg * 4 + e] = b; }
+    }
+    (void)bred;
+    __syncthreads();
+    if (tid < 32) {
+      const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+      atomicAdd(bnr_sums + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 32 + tid, (double)v);
+    }
+    __syncthreads();
+  }
+  // ---- weight gradient: lane holds D[tap = 4 kg + e][c = li]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int tap = kg * 4 + e;
+    if (tap < 9) red[wave][tap * 16 + li] = dwacc[e];
   }
   {
     const float v = wave_sum(gb);
@@ -1277,6 +1468,27 @@ static int head_bwd_impl(vk_dtype dtype, int N, int H, int W, const vk_src* src,
   const int tx = (W + 15) / 16, ty = (H + 15) / 16;
   const int ntiles = N * tx * ty;
   const double eb = dtype == VK_F32 ? 4.0 : 2.0;
+  // 16-bit types with the fused reduce of the SAME tensor the head reads (what the training plan asks for): one pass on the matrix cores
+  if (dtype != VK_F32 && bnr && bnr->z == src->ptr && bnr->scale == src->scale && bnr->shift == src->shift && src->scale && src->shift &&
+      !getenv("VK_HEAD_NO_MFMA")) {
+    vkh::ProfScope ps_("head_bwd_mfma", st, 4.0 * 144.0 * N * H * W, (double)N * H * W * (32.0 * eb + 4.0));
+    int nb = ntiles < 1024 ? ntiles : 1024;
+    float* part = nullptr;
+    if (workspace && workspace_bytes >= 148 * sizeof(float)) {
+      const size_t cap = workspace_bytes / (148 * sizeof(float));
+      if ((size_t)nb > cap) nb = (int)cap;
+      part = (float*)workspace;
+    }
+    if (dtype == VK_BF16)
+      hipLaunchKernelGGL(k_head_bwd_mfma<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, N, H, W, tx, ty, ntiles, (const bf16_t*)src->ptr, src->scale,
+                         src->shift, src->relu, w9x16, dlogits, (bf16_t*)dy, bnr->sums, dw9x16, dbias, part);
+    else
+      hipLaunchKernelGGL(k_head_bwd_mfma<f16_t>, dim3((unsigned)nb), dim3(256), 0, st, N, H, W, tx, ty, ntiles, (const f16_t*)src->ptr, src->scale,
+                         src->shift, src->relu, w9x16, dlogits, (f16_t*)dy, bnr->sums, dw9x16, dbias, part);
+    if (part) hipLaunchKernelGGL(k_head_wgrad_reduce, dim3(10), dim3(256), 0, st, nb, (const float*)part, dw9x16, dbias);
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
+  }
   {
     vkh::ProfScope ps_("head_dgrad", st, 2.0 * 144.0 * N * H * W, (double)N * H * W * (16.0 * eb + 4.0));
     const int nbd = ntiles < 2048 ? ntiles : 2048;
