@@ -534,6 +534,51 @@ def test_conv_wgrad(case, dtn, wgrad_path):
     assert err <= t, f"{err} > {t}"
 
 
+@pytest.mark.parametrize("dtn", ["bf16", "f16"])
+@pytest.mark.parametrize("up", [0, 1], ids=["plain", "up"])
+@pytest.mark.parametrize("K", [16, 32])
+@pytest.mark.parametrize("shape", [(2, 40, 40), (1, 70, 50), (3, 32, 96), (1, 132, 20)], ids=["40", "ragged", "wide", "tall"])
+def test_wgrad_stream_kernel(shape, K, up, dtn, monkeypatch):
+    """wgrad_stream_kernel (C = 32 single source, K = 16 / 32, optionally nearest-x2 upsampled: decoder block 3 conv2 / block 4 conv1)
+    against fp64 autograd AND against the tile kernel it replaces (VK_NO_WSTREAM=1) on the same inputs: strips with 1..N steps per
+    wave (every phase of the ring / queue unrolling), ragged widths, maps shorter than a strip; reproducible (two runs, same bits)."""
+    dt = DT[dtn]
+    N, H, W = shape
+    Hs, Wsrc = (H // 2, W // 2) if up else (H, W)
+    x = gen(N, 32, Hs, Wsrc, seed=301)
+    dz = gen(N, K, H, W, seed=302)
+    sc_c = 0.5 + torch.rand(32, generator=torch.Generator().manual_seed(303))
+    sh_c = gen(32, seed=304, scale=0.3)
+    v = rnd(torch.relu(rnd(x, dt) * sc_c.view(1, -1, 1, 1) + sh_c.view(1, -1, 1, 1)), dt)
+    if up:
+        v = F.interpolate(v, scale_factor=2, mode="nearest")
+    wv = torch.zeros(K, 32, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(v.double(), wv, padding=1).backward(rnd(dz, dt).double())
+    ref = wv.grad.float()
+    xd, dzd = to_nhwc(x, dt), to_nhwc(dz, dt)
+    d = conv_desc(dt, N, H, W, H, W, K, 3, 1, 1, 0, mk_src(xd, 32, up, D(sc_c), D(sh_c), 1))
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev())
+    monkeypatch.setenv("VK_WH_MINBLOCKS", "1")
+    monkeypatch.setenv("VK_WH_MAXCOMBO", "1000")
+    monkeypatch.setenv("VK_WS_KW", "32" if (N + H) % 2 else "16")          # K = 32: one 32-wide or two 16-wide slices per wave
+
+    def run(flag):
+        if flag:
+            monkeypatch.setenv("VK_NO_WSTREAM", "1")
+        else:
+            monkeypatch.delenv("VK_NO_WSTREAM", raising=False)
+        dw = torch.zeros(K, 3, 3, 32, dtype=torch.float32, device=dev())
+        vk._lib.check(vk.lib().vk_conv_wgrad(C.byref(d), dzd.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), st()))
+        torch.cuda.synchronize()
+        return dw
+
+    a, b, tile = run(False), run(False), run(True)
+    assert torch.equal(a, b)
+    scale = ref.abs().max().item() + 1e-6
+    assert (a.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-3 * scale
+    assert (a - tile).abs().max().item() <= 1e-4 * scale          # same operands, fp32 accumulation in another order
+
+
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
 def test_conv_wgrad_upsample_concat(dtn, wgrad_path):
     dt = DT[dtn]

@@ -478,6 +478,277 @@ __global__ __launch_bounds__(256) void k_wgrad_slab_reduce(size_t n4, int splits
   }
 }
 
+// ---- streaming form for the 32-channel inputs of decoder blocks 3 / 4 (r03): C = 32 (one source, optionally nearest-x2 upsampled),
+// K = 16 or 32, 16-bit types.  These launches move 0.27-0.34 GB for 10-20 GFLOP (HBM-bound, floors 54 / 67 us) and the tile kernel
+// runs them at 121 / 188 us: every 128-pixel tile is a load -> transform -> LDS -> barrier -> 18-36 MFMAs chain.  Here, as in
+// conv3x3_stream_kernel, every WAVE is its own pipeline and the only workgroup barriers are those of the final reduction:
+//   * a wave owns a strip of 16 columns x RS rows of one image and walks down it two rows (= one K = 32 MFMA step) at a time, the whole
+//     K x 9 x 32 output in its accumulators (18 / 36 tiles);
+//   * per step it needs two new dz rows and two new V rows (one SOURCE row when upsampled: each source pixel goes to its two halo
+//     columns, each source row serves two steps' worth of taps), BN+ReLU-transformed once and written once to the wave's private LDS
+//     ring; the rows of the next steps are in flight in registers (queue depth = ring period, indices compile-time);
+//   * fragments are the LDS-transposed reads of wgrad_halo_kernel (pixels along the MFMA reduction), the dz fragments shared by the
+//     nine taps: (2 TK + 36) reads per 18 TK MFMAs;
+//   * at the end the four waves of a workgroup add their tiles in LDS in a fixed order and the workgroup writes ONE slab
+//     (k_wgrad_slab_reduce adds the workgroups in order: reproducible).
+template <typename T, int K, bool UP>
+struct WsCfg {
+  static constexpr int C = 32, TK = K / 16, TCc = 2;
+  static constexpr int VSB = 96, ZSB = K == 16 ? 32 : 96;            // pixel strides of the transposed reads (WhCfg::zpad)
+  static constexpr int VROW = 18 * VSB, ZROW = 16 * ZSB;
+  static constexpr int PER = UP ? 4 : 3;                              // ring period in steps = look-ahead depth
+  static constexpr int NVS = UP ? 4 : 6, NZS = UP ? 8 : 6;            // ring slots: V (source) rows, dz rows
+  static constexpr int WAVE_LDS = NVS * VROW + NZS * ZROW;
+  static constexpr int RED = K * 9 * C * 4;
+  static constexpr int SMEM = 4 * WAVE_LDS > RED ? 4 * WAVE_LDS : RED;
+  static constexpr int NVL = UP ? 1 : 3;                              // V vectors per lane and step (40 / 144 vectors)
+  static constexpr int NZL = K / 16;                                  // dz vectors per lane and step (64 / 128 vectors)
+};
+
+// Work unit = (strip, 32-channel chunk of the source, K-wide slice of the output channels): one wave each; the four waves of a workgroup
+// are four strips of the SAME (chunk, slice) = blockIdx.y, so their tiles add up.  p.K / p.C: channel counts of dz / of the whole
+// (concatenated) input, p.s0: THIS launch's source (its own channel stride), c_dst0: where that source starts in the concatenation.
+struct WsArgs {
+  int RS, c_dst0, nks;
+};
+
+#ifndef VK_WS_MINWG
+#define VK_WS_MINWG 2
+#endif
+template <typename T, int K, bool UP>
+__global__ __launch_bounds__(256, (K == 16 ? (UP ? VK_WS_MINWG : 2) : 1)) void wgrad_stream_kernel(const WhParams p, const WsArgs wa) {
+  using Cfg = WsCfg<T, K, UP>;
+  const int RS = wa.RS;
+  const int chunk = (int)blockIdx.y / wa.nks, kslice = (int)blockIdx.y - chunk * wa.nks;
+  const int cl0 = chunk * 32, kbase = kslice * K, Cs = p.s0.C;
+  constexpr int TK = Cfg::TK, TCc = Cfg::TCc, VSB = Cfg::VSB, ZSB = Cfg::ZSB, VROW = Cfg::VROW, ZROW = Cfg::ZROW;
+  constexpr int PER = Cfg::PER, NVS = Cfg::NVS, NZS = Cfg::NZS, NVL = Cfg::NVL, NZL = Cfg::NZL, VE = 8, C = 32;
+  static_assert(sizeof(T) == 2, "16-bit element types");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* const Vr = smem + wave * Cfg::WAVE_LDS;
+  char* const Zr = Vr + NVS * VROW;
+  const int strips_x = (p.W + 15) / 16, strips_y = (p.H + RS - 1) / RS;
+  int sid = (int)blockIdx.x * 4 + wave;
+  const bool active = sid < p.N * strips_y * strips_x;
+  const int sx = sid % strips_x;
+  sid /= strips_x;
+  const int sy = sid % strips_y;
+  const int n = sid / strips_y;
+  const int x0 = sx * 16, ys = sy * RS, ye = min(p.H, ys + RS);
+  const __amdgpu_buffer_rsrc_t rsv = make_rsrc(p.s0.ptr, p.s0.bytes);
+  const __amdgpu_buffer_rsrc_t rsz = make_rsrc(p.dz, p.dz_bytes);
+  const bool affine = p.s0.scale != nullptr, relu = p.s0.relu != 0;
+  const int Hs = p.H >> (UP ? 1 : 0), Ws = p.W >> (UP ? 1 : 0);
+
+  f32x4_t acc[9][TK][TCc];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int a = 0; a < TK; ++a)
+#pragma unroll
+      for (int b = 0; b < TCc; ++b) acc[t][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  if (active) {
+    // ---- staging geometry (fixed for the strip)
+    // V: vector v = lane + 64 q -> (row of the pair, halo / source pixel, 16-byte piece); every lane's vectors cover the same 8 channels
+    float sc[VE], sh[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+      sc[j] = affine ? p.s0.scale[cl0 + (lane & 3) * VE + j] : 1.f;
+      sh[j] = affine ? p.s0.shift[cl0 + (lane & 3) * VE + j] : 0.f;
+    }
+    int v_rowsel[NVL], v_col[NVL], v_goff[NVL];
+    bool v_ok[NVL];
+#pragma unroll
+    for (int q = 0; q < NVL; ++q) {
+      const int v = lane + 64 * q;
+      if (UP) {
+        const int j = v >> 2;                                // source pixel 0..9 <-> source column x0/2 - 1 + j
+        const int cs = (x0 >> 1) - 1 + j;
+        v_rowsel[q] = 0;
+        v_col[q] = j;
+        v_ok[q] = v < 40 && (unsigned)cs < (unsigned)Ws;
+        v_goff[q] = cs * Cs + cl0 + (v & 3) * VE;
+      } else {
+        const int rs_ = v / 72, hp = (v - rs_ * 72) >> 2;    // 72 vectors per row
+        const int xs = x0 - 1 + hp;
+        v_rowsel[q] = rs_;
+        v_col[q] = hp;
+        v_ok[q] = v < 144 && (unsigned)xs < (unsigned)p.W;
+        v_goff[q] = xs * Cs + cl0 + (v & 3) * VE;
+      }
+    }
+    int z_rowsel[NZL], z_px[NZL], z_pc[NZL];
+    bool z_ok[NZL];
+#pragma unroll
+    for (int q = 0; q < NZL; ++q) {
+      const int v = lane + 64 * q;
+      constexpr int VPR = 16 * (K / 8);                       // vectors per dz row
+      z_rowsel[q] = v / VPR;
+      z_px[q] = (v % VPR) / (K / 8);
+      z_pc[q] = v % (K / 8);
+      z_ok[q] = x0 + z_px[q] < p.W;
+    }
+    // requests: V row(s) and dz rows that step s adds (s >= 0; the prologue issues the rows of step 0 separately)
+    auto issue_v = [&](int row, int rowsel_only, u32x4_t (&r)[NVL]) {     // non-UP: `row` = first of the two rows; UP: the source row
+#pragma unroll
+      for (int q = 0; q < NVL; ++q) {
+        const int rr = row + v_rowsel[q];
+        const bool ok = v_ok[q] && (unsigned)rr < (unsigned)Hs && (rowsel_only < 0 || v_rowsel[q] == rowsel_only);
+        r[q] = buf_load16(rsv, ok ? (uint32_t)(((n * Hs + rr) * Ws) * Cs + v_goff[q]) * 2u : kOOB);
+      }
+    };
+    auto issue_z = [&](int row, u32x4_t (&r)[NZL]) {                      // dz rows row, row + 1 (zeros beyond the strip's end)
+#pragma unroll
+      for (int q = 0; q < NZL; ++q) {
+        const int rr = row + z_rowsel[q];
+        const bool ok = z_ok[q] && rr < ye;
+        r[q] = buf_load16(rsz, ok ? (uint32_t)(((n * p.H + rr) * p.W + x0 + z_px[q]) * p.K + kbase + z_pc[q] * VE) * 2u : kOOB);
+      }
+    };
+    // ring writes.  V: transform, zero outside the map (the buffer load returned zeros there, the affine must not turn them into shift)
+    auto write_v = [&](int row, int slot0, const u32x4_t (&r)[NVL]) {     // non-UP: rows row, row + 1 -> slots slot0, slot0 + 1 (mod NVS)
+#pragma unroll
+      for (int q = 0; q < NVL; ++q) {
+        const int v = lane + 64 * q;
+        if (v >= (UP ? 40 : 144)) continue;
+        const int rr = row + v_rowsel[q];
+        u32x4_t x = r[q];
+        if (affine) x = AffineRelu<T>::run(x, sc, sh, relu);
+        if (!(v_ok[q] && (unsigned)rr < (unsigned)Hs)) x = u32x4_t{0, 0, 0, 0};
+        char* const dst = Vr + ((slot0 + v_rowsel[q]) % NVS) * VROW + (v & 3) * 16;
+        if (UP) {
+          const int j = v_col[q];                            // source pixel j -> halo columns 2j - 1, 2j
+          if (j > 0) *reinterpret_cast<u32x4_t*>(dst + (2 * j - 1) * VSB) = x;
+          if (j < 9) *reinterpret_cast<u32x4_t*>(dst + (2 * j) * VSB) = x;
+        } else {
+          *reinterpret_cast<u32x4_t*>(dst + v_col[q] * VSB) = x;
+        }
+      }
+    };
+    auto write_z = [&](int slot0, const u32x4_t (&r)[NZL]) {
+#pragma unroll
+      for (int q = 0; q < NZL; ++q)
+        *reinterpret_cast<u32x4_t*>(Zr + ((slot0 + z_rowsel[q]) % NZS) * ZROW + z_px[q] * ZSB + z_pc[q] * 16) = r[q];
+    };
+    // transposed-read lane geometry (wgrad_halo_kernel): lane j of 16-lane group g supplies pixel 4 g + (j >> 2), channels 4 (j & 3) ..
+    const int lane_z = (4 * (lane >> 4) + ((lane & 15) >> 2)) * ZSB + (4 * (lane & 3)) * 2;
+    const int lane_v = (4 * (lane >> 4) + ((lane & 15) >> 2)) * VSB + (4 * (lane & 3)) * 2;
+    auto tr = [](const char* q) { return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q))); };
+
+    // ---- prologue.  Ring slots: non-UP  V row ys - 1 + i -> slot i % 6, dz row ys + j -> slot (j + 1) % 6;
+    //                            UP      source row ys/2 - 1 + i -> slot i % 4, dz row ys + j -> slot j % 8
+    u32x4_t vq[PER][NVL], zq[PER][NZL];
+    const int ss = ys >> 1;
+    if (UP) {
+      u32x4_t v0[NVL], v1[NVL], v2[NVL], z0[NZL];
+      issue_v(ss - 1, -1, v0);
+      issue_v(ss, -1, v1);
+      issue_v(ss + 1, -1, v2);
+      issue_z(ys, z0);
+#pragma unroll
+      for (int s_ = 1; s_ < PER; ++s_) { issue_v(ss + 1 + s_, -1, vq[s_]); issue_z(ys + 2 * s_, zq[s_]); }     // step s_ adds source row ss + s_ + 1
+      write_v(ss - 1, 0, v0);
+      write_v(ss, 1, v1);
+      write_v(ss + 1, 2, v2);
+      write_z(0, z0);
+    } else {
+      u32x4_t v0[NVL], v1[NVL], z0[NZL];
+      issue_v(ys - 1, -1, v0);                               // rows ys - 1, ys
+      issue_v(ys + 1, -1, v1);                               // rows ys + 1, ys + 2
+      issue_z(ys, z0);
+#pragma unroll
+      for (int s_ = 1; s_ < PER; ++s_) { issue_v(ys + 2 * s_ + 1, -1, vq[s_]); issue_z(ys + 2 * s_, zq[s_]); }   // step s_ adds V rows ys + 2 s_ + 1, + 2
+      write_v(ys - 1, 0, v0);
+      write_v(ys + 1, 2, v1);
+      write_z(1, z0);
+    }
+
+    auto step = [&](int t, auto ph_c) {
+      constexpr int PH = decltype(ph_c)::value;              // t mod PER
+      const int y = ys + 2 * t;
+      // rows of step t + PER into the queue slot whose content went into the ring one step ago
+      if (UP) issue_v(ss + 1 + t + PER, -1, vq[PH]);
+      else issue_v(y + 2 * PER + 1, -1, vq[PH]);
+      issue_z(y + 2 * PER, zq[PH]);
+      // ---- fragments and MFMAs
+      const char* const Z0 = Zr + (UP ? (2 * PH) % NZS : (2 * PH + 1) % NZS) * ZROW + lane_z;
+      const char* const Z1 = Zr + (UP ? (2 * PH + 1) % NZS : (2 * PH + 2) % NZS) * ZROW + lane_z;
+      u32x4_t zf[TK];
+#pragma unroll
+      for (int a = 0; a < TK; ++a) {
+        const u32x2_t lo = tr(Z0 + a * 32), hi = tr(Z1 + a * 32);
+        zf[a] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        // output rows y, y + 1 see V rows y - 1 + r, y + r
+        const int slo = UP ? (PH + (r + 1) / 2) % NVS : (2 * PH + r) % NVS;          // UP: source rows (y - 1 + r) >> 1, (y + r) >> 1, y even
+        const int shi = UP ? (PH + (r + 2) / 2) % NVS : (2 * PH + r + 1) % NVS;
+#pragma unroll
+        for (int sx_ = 0; sx_ < 3; ++sx_) {
+          u32x4_t vf[TCc];
+#pragma unroll
+          for (int b = 0; b < TCc; ++b) {
+            const u32x2_t lo = tr(Vr + slo * VROW + sx_ * VSB + lane_v + b * 32), hi = tr(Vr + shi * VROW + sx_ * VSB + lane_v + b * 32);
+            vf[b] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+          }
+#pragma unroll
+          for (int a = 0; a < TK; ++a)
+#pragma unroll
+            for (int b = 0; b < TCc; ++b) acc[r * 3 + sx_][a][b] = Mma<T>::run(zf[a], vf[b], acc[r * 3 + sx_][a][b]);
+        }
+      }
+      // ---- the rows step t + 1 adds: into slots this step does not read
+      if (UP) {
+        write_v(ss + 2 + t, (PH + 3) % NVS, vq[(PH + 1) % PER]);
+        write_z((2 * PH + 2) % NZS, zq[(PH + 1) % PER]);
+      } else {
+        write_v(y + 3, (2 * PH + 4) % NVS, vq[(PH + 1) % PER]);
+        write_z((2 * PH + 3) % NZS, zq[(PH + 1) % PER]);
+      }
+    };
+    const int nsteps = (ye - ys + 1) >> 1;
+    for (int t = 0; t < nsteps; t += PER) {
+      step(t, std::integral_constant<int, 0>{});
+      if (t + 1 < nsteps) step(t + 1, std::integral_constant<int, 1>{});
+      if (t + 2 < nsteps) step(t + 2, std::integral_constant<int, 2>{});
+      if constexpr (PER == 4) {
+        if (t + 3 < nsteps) step(t + 3, std::integral_constant<int, 3>{});
+      }
+    }
+  }
+
+  // ---- the four waves add their tiles in wave order; one slab per workgroup
+  __syncthreads();                                             // every wave is done with its ring
+  float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+  for (int phase = 0; phase < 4; ++phase) {
+    if (wave == phase) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < TK; ++a)
+#pragma unroll
+          for (int b = 0; b < TCc; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = a * 16 + (lane >> 4) * 4 + e, c = b * 16 + (lane & 15);
+              float* dst = red + (k * 9 + t) * C + c;
+              if (phase > 0) *dst += acc[t][a][b][e];
+              else *dst = acc[t][a][b][e];
+            }
+    }
+    __syncthreads();
+  }
+  float* const slab = p.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * K * 9 * C;
+  for (int i = tid; i < K * 9 * C / 4; i += 256)
+    *reinterpret_cast<f32x4_t*>(slab + i * 4) = *reinterpret_cast<const f32x4_t*>(red + i * 4);
+}
+
 // ------------------------------------------------------------------------------------------------ host
 // tuning knobs, read per call so that tests can force the kernel onto small problems
 static int wh_max_combo() { const char* e = getenv("VK_WH_MAXCOMBO"); return e ? atoi(e) : 64; }
@@ -533,8 +804,106 @@ void launch_slab_reduce(size_t n4, int splits, const float* slab, float* dw, hip
   hipLaunchKernelGGL(k_wgrad_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, n4, splits, slab, dw);
 }
 
+// dw[(kbase + k)][tap][c_dst + c] += sum over the nwg workgroup tiles [KW][9][32] of one (chunk, slice), in workgroup order (same
+// lane split as k_wgrad_slab_reduce: 16 lanes per float4, each adding every 16th tile, then the 16 partial sums in lane order)
+__global__ __launch_bounds__(256) void k_ws_slab_reduce(int KW, int Ctot, int c_dst0, int nks, int nwg, const float* __restrict__ slab, float* __restrict__ dw) {
+  __shared__ f32x4_t red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int n4 = KW * 9 * 8;
+  const int e = (int)blockIdx.x * 16 + tx;
+  const int chunk = (int)blockIdx.y / nks, kslice = (int)blockIdx.y - chunk * nks;
+  const float* const base = slab + (size_t)blockIdx.y * nwg * n4 * 4;
+  f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (e < n4) {
+    int s_ = ty;
+    for (; s_ + 48 < nwg; s_ += 64) {                      // four loads in flight per lane (the tiles come from HBM)
+      const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(base + ((size_t)s_ * n4 + e) * 4);
+      const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(base + ((size_t)(s_ + 16) * n4 + e) * 4);
+      const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(base + ((size_t)(s_ + 32) * n4 + e) * 4);
+      const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(base + ((size_t)(s_ + 48) * n4 + e) * 4);
+      a = a + v0; a = a + v1; a = a + v2; a = a + v3;
+    }
+    for (; s_ < nwg; s_ += 16) a = a + *reinterpret_cast<const f32x4_t*>(base + ((size_t)s_ * n4 + e) * 4);
+  }
+  red[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && e < n4) {
+    const int row = e >> 3, c4 = e & 7;                   // row = k * 9 + tap inside the slice
+    float* const dst = dw + ((size_t)(kslice * KW * 9 + row)) * Ctot + c_dst0 + chunk * 32 + c4 * 4;
+    f32x4_t t = *reinterpret_cast<const f32x4_t*>(dst);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t = t + red[j][tx];
+    *reinterpret_cast<f32x4_t*>(dst) = t;
+  }
+}
+
+// the 32-channel-chunk layers of decoder blocks 3 / 4 on the streaming kernel: one launch per source (needs the slab workspace: it has
+// no atomics epilogue).  Returns the slab bytes it used through *used.
+template <typename T, int KW, bool UP>
+static int launch_ws(WhParams p, int c_dst0, char* slab, size_t slab_bytes, size_t* used, hipStream_t st) {
+  using Cfg = WsCfg<T, KW, UP>;
+  const int nchunk = p.s0.C / 32, nks = p.K / KW, gy = nchunk * nks;
+  // strips of 16 columns x RS rows, one per wave: enough waves for ~two rounds of the chip, RS even
+  int RS = p.H;
+  const long per_image = (long)((p.W + 15) / 16);
+  // exactly ONE round of resident waves (measured: D3c2 73 / 93 / 134 us at 1 / 2 / 4 rounds, D4c1 132 / 105 / 118 us at 0.5 / 1 / 2):
+  // 36 accumulator tiles run one wave per SIMD (1024 waves), 18 tiles two (2048)
+  const long want = KW == 32 ? 1024 : 1024 * (UP ? VK_WS_MINWG : 2);
+  const long want_e = getenv("VK_WS_WANT") ? atol(getenv("VK_WS_WANT")) : 0;
+  while (RS > 32 && (long)p.N * per_image * ((p.H + RS - 1) / RS) * gy < (want_e ? want_e : want)) RS >>= 1;
+  RS = (RS + 1) & ~1;
+  const long strips = (long)p.N * per_image * ((p.H + RS - 1) / RS);
+  const long nwg = (strips + 3) / 4;
+  *used = (size_t)nwg * gy * KW * 9 * 32 * sizeof(float);
+  if (*used > slab_bytes) return VK_ERR_UNSUPPORTED;
+  static bool attr_done = false;
+  if (!attr_done && Cfg::SMEM > 64 * 1024) {
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_stream_kernel<T, KW, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+    attr_done = true;
+  }
+  p.slab = (float*)slab;
+  WsArgs wa{RS, c_dst0, nks};
+  {
+    static const std::string tag = std::string("wgrad_stream_16b_c32") + (UP ? "up" : "") + "_k" + std::to_string(KW);
+    const double bytes = ((double)p.N * (p.H >> (UP ? 1 : 0)) * (p.W >> (UP ? 1 : 0)) * p.s0.C + (double)p.N * p.H * p.W * p.K) * 2.0 + 9.0 * p.K * p.s0.C * 4.0;
+    vkh::ProfScope ps(tag.c_str(), st, 2.0 * (double)p.N * p.H * p.W * p.K * 9.0 * p.s0.C, bytes);
+    hipLaunchKernelGGL((wgrad_stream_kernel<T, KW, UP>), dim3((unsigned)nwg, (unsigned)gy), dim3(256), Cfg::SMEM, st, p, wa);
+  }
+  {
+    vkh::ProfScope ps("wgrad_slab_reduce", st, 0.0, (double)*used + 2.0 * p.K * 9.0 * p.s0.C * 4.0);
+    hipLaunchKernelGGL(k_ws_slab_reduce, dim3((unsigned)((KW * 9 * 8 + 15) / 16), (unsigned)gy), dim3(256), 0, st, KW, p.C, c_dst0, nks, (int)nwg,
+                       (const float*)slab, p.dw);
+  }
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+// Routed here: ONE source of exactly 32 channels (decoder block 3 conv2, block 4 conv1).  The kernel's work units also cover several
+// 32-channel chunks and two sources (decoder block 3 conv1: 64 upsampled + 64 skip channels) — built and measured: every chunk
+// re-reads dz and every K slice re-reads V, 294-466 us against the tile kernel's 230 us (profiles/r03/wgrad_stream_ab.log), so the
+// host does not send those layers.  VK_NO_WSTREAM=1: the tile kernels instead (tests / A-B);  VK_WS_KW=16: K = 32 as two 16-wide
+// slices (two waves per SIMD; measured slower than one 32-wide slice: 115 vs 100 us).
+template <typename T>
+static int ws_try(const WhParams& p, size_t slab_bytes, hipStream_t st) {
+  if constexpr (sizeof(T) != 2) return VK_ERR_UNSUPPORTED;
+  else {
+    if (!p.slab || getenv("VK_NO_WSTREAM") || getenv("VK_WH_NO_SLAB")) return VK_ERR_UNSUPPORTED;
+    if ((p.K != 16 && p.K != 32) || p.s1.ptr || p.s0.C != 32 || p.C != 32) return VK_ERR_UNSUPPORTED;
+    if (p.s0.up && ((p.H | p.W) & 1)) return VK_ERR_UNSUPPORTED;
+    const char* e = getenv("VK_WS_KW");
+    const int kw = (p.K == 32 && e && atoi(e) == 16) ? 16 : p.K;
+    size_t used = 0;
+    if (kw == 32) return p.s0.up ? launch_ws<T, 32, true>(p, 0, (char*)p.slab, slab_bytes, &used, st) : launch_ws<T, 32, false>(p, 0, (char*)p.slab, slab_bytes, &used, st);
+    return p.s0.up ? launch_ws<T, 16, true>(p, 0, (char*)p.slab, slab_bytes, &used, st) : launch_ws<T, 16, false>(p, 0, (char*)p.slab, slab_bytes, &used, st);
+  }
+}
+
 template <typename T>
 static int wh_select(const WhParams& p, int cgran, size_t slab_bytes, hipStream_t st) {
+  {
+    const int rc = ws_try<T>(p, slab_bytes, st);
+    if (rc != VK_ERR_UNSUPPORTED) return rc;
+  }
   // cgran: channel granularity that keeps a c-tile inside one concat source
   if constexpr (sizeof(T) == 2) {      // fp32 double-buffered 64x64 stages would need 197 KB of LDS
     if (p.K >= 64 && cgran % 64 == 0) {
