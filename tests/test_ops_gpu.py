@@ -1153,3 +1153,74 @@ def test_comm_c_abi_single_rank():
     finally:
         L_.check(lib.vk_comm_destroy(h), "vk_comm_destroy")
     assert lib.vk_comm_init(2, 2, ident, C.byref(h)) < 0          # rank outside [0, world)
+
+
+# ------------------------------------------------------------------------------------------------ streaming convolution kernels vs tile kernels
+STREAM_ROUTES = [
+    # name, C_in, up, K, mode (0 forward + statistics, 2 data gradient + fused reduce, 3 the same behind the 2x2 pooling)
+    ("dec4_conv1_fwd", 32, 1, 16, 0), ("dec4_conv2_fwd", 16, 0, 16, 0), ("dec3_conv2_fwd", 32, 0, 32, 0),
+    ("dec4_conv2_dgrad", 16, 0, 16, 2), ("dec3_conv2_dgrad", 32, 0, 32, 2), ("dec4_conv1_dgrad", 16, 0, 32, 3),
+]
+
+
+@pytest.mark.parametrize("dtn", ["bf16", "f16"])
+@pytest.mark.parametrize("rs", ["8", "24", "64", ""], ids=["rs8", "rs24", "rs64", "auto"])
+@pytest.mark.parametrize("route", STREAM_ROUTES, ids=[r[0] for r in STREAM_ROUTES])
+def test_stream_conv_kernels_match_tile_kernels(route, rs, dtn, monkeypatch):
+    """conv3x3_stream_kernel (decoder blocks 3 / 4) against the tile kernels it replaces (VK_NO_STREAM=1) at several strip heights
+    (VK_STREAM_RS; the launcher picks 32-256 rows by map size): the same bits at C = 16, fp32 accumulation order at C = 32; the
+    BatchNorm / BN-backward sums agree to fp32 summation order.  Map 72 x 40: strips with full and ragged ends at every height."""
+    _, Cin, up, K, mode = route
+    dt = DT[dtn]
+    lib = L_.lib()
+    N, H, W = 2, 72, 40
+    if rs:
+        monkeypatch.setenv("VK_STREAM_RS", rs)
+    else:
+        monkeypatch.delenv("VK_STREAM_RS", raising=False)
+    Hs, Wsrc = (H // 2, W // 2) if up else (H, W)
+    x = D(gen(N, Hs, Wsrc, Cin, seed=401).to(dt))
+    sc, sh = D(torch.rand(Cin, generator=torch.Generator().manual_seed(402)) + 0.5), D(gen(Cin, seed=403, scale=0.1))
+    none = L_.vk_src(None, 0, 0, None, None, 0)
+    w = D((gen(K, 3, 3, Cin, seed=404) * 0.05).to(dt))
+    Ho, Wo = (H // 2, W // 2) if mode == 3 else (H, W)
+    zprev = D(gen(N, Ho, Wo, K, seed=405).to(dt))
+    bsc, bsh = D(torch.rand(K, generator=torch.Generator().manual_seed(406)) + 0.5), D(gen(K, seed=407, scale=0.1))
+    if mode == 0:
+        d = L_.vk_conv_desc(L_.dtype_code(dt), N, H, W, H, W, K, 3, 3, 1, 1, 0, L_.vk_src(x.data_ptr(), Cin, up, sc.data_ptr(), sh.data_ptr(), 1), none)
+    else:
+        d = L_.vk_conv_desc(L_.dtype_code(dt), N, H, W, H, W, K, 3, 3, 1, 1, 1, L_.vk_src(x.data_ptr(), Cin, 0, None, None, 0), none)
+    packed = lib.vk_conv_uses_halo_pack(C.byref(d)) != 0
+    wp = torch.empty_like(w)
+    KEEP.append(wp)
+    if packed:
+        L_.check(lib.vk_halo_pack(L_.dtype_code(dt), K, Cin, w.data_ptr(), wp.data_ptr(), st()))
+    else:
+        wp.copy_(w)
+
+    def run(no_stream):
+        if no_stream:
+            monkeypatch.setenv("VK_NO_STREAM", "1")
+        else:
+            monkeypatch.delenv("VK_NO_STREAM", raising=False)
+        y = torch.full((N, Ho, Wo, K), float("nan"), device=dev(), dtype=dt)
+        sums = torch.zeros(REPL * 2 * K, dtype=torch.float64, device=dev())
+        if mode == 0:
+            fn = lib.vk_conv_fwd_packed if packed else lib.vk_conv_fwd
+            L_.check(fn(C.byref(d), wp.data_ptr(), y.data_ptr(), None, 0, 0, sums.data_ptr(), st()))
+        else:
+            bnr = L_.vk_bnr(zprev.data_ptr(), bsc.data_ptr(), bsh.data_ptr(), sums.data_ptr())
+            L_.check(lib.vk_conv_dgrad_fused(C.byref(d), wp.data_ptr(), y.data_ptr(), None, 0, 1 if mode == 3 else 0, C.byref(bnr), st()))
+        torch.cuda.synchronize()
+        return y, sums.view(REPL, 2, K).sum(0)
+
+    (ya, sa), (yb, sb) = run(True), run(False)
+    assert not torch.isnan(yb.float()).any()
+    if Cin == 16:          # one reduction step per tap pair in both kernels: the same bits
+        assert torch.equal(ya, yb), (ya.float() - yb.float()).abs().max().item()
+    else:                  # C = 32: the tile kernels add (filter column, filter row), the streaming kernel tap by tap -> fp32 rounding order
+        diff = (ya.float() - yb.float()).abs()
+        assert diff.max().item() <= tol(dt, ya.float()) * 0.5
+        assert (diff > 0).float().mean().item() < 0.05          # a last-bit flip of the stored 16-bit value here and there
+    # sums over the stored values: fp32 summation order at C = 16; at C = 32 also the flipped last bits (~ sqrt(n) ulp)
+    assert torch.allclose(sa, sb, rtol=1e-5, atol=(1e-5 if Cin == 16 else 5e-3) * (1.0 + sa.abs().max().item()))

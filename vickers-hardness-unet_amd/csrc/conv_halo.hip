@@ -1962,8 +1962,10 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const HaloParams p) {
 //     16-channel tile;
 //   * output rows leave straight from the accumulators (lane = 4 consecutive channels of one pixel: 8-byte stores, 512 contiguous
 //     bytes per row for K = 16); BatchNorm sums stay in registers for the whole strip and become 16 fp64 atomics per wave at its end.
-// Arithmetic per output element is the same as in the tile kernels (same MFMA operand order per accumulator: taps in ascending
-// order, one chunk), statistics are over the stored (rounded) values, pooling adds the four rounded values in the tile kernels' order.
+// Arithmetic per output element: taps in ascending order, one chunk — at C = 16 that is the tile kernel's order (the same bits), at
+// C = 32 the tile kernels add (filter column, filter row) instead: results differ in fp32 rounding order (a last-bit flip of the
+// stored value on < 5 % of the elements, tests/test_ops_gpu.py::test_stream_conv_kernels_match_tile_kernels).  Statistics are over the
+// stored (rounded) values, pooling adds the four rounded values in the tile kernels' order.
 template <typename T, int CIN, bool UP>
 struct StreamCfg {
   static constexpr int NSTEP = CIN == 16 ? 5 : 9;
@@ -1988,7 +1990,8 @@ template <typename T, int CIN, int TC, bool UP, int MODE>
 __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p) {
   using Cfg = StreamCfg<T, CIN, UP>;
   constexpr int NSTEP = Cfg::NSTEP, APS = Cfg::APS, VPP = Cfg::VPP, NVEC = Cfg::NVEC, NLD = Cfg::NLD, ROWB = Cfg::ROWB;
-  constexpr int RS = Cfg::RS, VE = 8;
+  constexpr int VE = 8;
+  const int RS = p.tiles_y;                                // strip height (launch_stream): a multiple of 8
   constexpr bool BNR = MODE >= 2, POOL = MODE == 3;
   static_assert(sizeof(T) == 2, "16-bit element types");
   static_assert(!(UP && MODE != 0), "the upsampled source occurs in forward launches only");
@@ -2568,7 +2571,22 @@ static int launch_s2dg(HaloParams p, hipStream_t st) {
 template <typename T, int CIN, int TC, bool UP, int MODE>
 static int launch_stream(const HaloParams& p, hipStream_t st) {
   using Cfg = StreamCfg<T, CIN, UP>;
-  const long strips = (long)p.N * ((p.H + Cfg::RS - 1) / Cfg::RS) * ((p.W + 15) / 16);
+  HaloParams q = p;
+  // strip height: as tall as leaves >= 4096 strips (two rounds of the 2048 resident waves) — fewer prologues and statistics atomics
+  // per output row; measured (profiles/r03/stream_strip_height.log): 512^2 maps best at 128 rows (dec4.conv2 data gradient + reduce
+  // 185 -> 153 us), 256^2 maps at 32-64 (128 rows = 1024 strips: 75 -> 101 us).  VK_STREAM_RS overrides (tests / sweeps).
+  const char* e_rs = getenv("VK_STREAM_RS");
+  int RS = Cfg::RS;
+  if (e_rs) {
+    RS = atoi(e_rs);
+  } else {
+    const long per_row_block = (long)p.N * ((p.W + 15) / 16);
+    while (RS * 2 <= 256 && per_row_block * ((p.H + 2 * RS - 1) / (2 * RS)) >= 4096) RS *= 2;
+  }
+  RS = (RS + 7) & ~7;
+  if (RS < 8) RS = 8;
+  q.tiles_y = RS;
+  const long strips = (long)p.N * ((p.H + RS - 1) / RS) * ((p.W + 15) / 16);
   dim3 grid((unsigned)((strips + 3) / 4), 1, 1);
   static const std::string tag_f = std::string("stream_16b_c") + std::to_string(CIN) + (UP ? "up" : "") + "_k" + std::to_string(TC * 16);
   static const std::string tag_d = tag_f + "_dgrad";
@@ -2577,7 +2595,7 @@ static int launch_stream(const HaloParams& p, hipStream_t st) {
   const double out_px = (double)p.N * p.H * p.W * (p.pool2 ? 0.25 : 1.0);
   const double bytes = (in_px * CIN + out_px * p.K * (p.bnr_z ? 2.0 : 1.0) + 9.0 * p.K * CIN) * 2.0;
   vkh::ProfScope ps(tag.c_str(), st, 2.0 * (double)p.N * p.H * p.W * p.K * 9.0 * CIN, bytes);
-  hipLaunchKernelGGL((conv3x3_stream_kernel<T, CIN, TC, UP, MODE>), grid, dim3(256), Cfg::SMEM, st, p);
+  hipLaunchKernelGGL((conv3x3_stream_kernel<T, CIN, TC, UP, MODE>), grid, dim3(256), Cfg::SMEM, st, q);
   VK_CHECK_HIP(hipGetLastError());
   return VK_OK;
 }
