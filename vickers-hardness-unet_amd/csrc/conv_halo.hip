@@ -2119,39 +2119,48 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
     for (int e = 0; e < 4; ++e) f[e] = g[e];
     return u32x2_t{pk[0], pk[1]};
   };
-  // element offset of this lane's 4 channels (tile a) at output row y (pooled modes: the half-resolution pixel)
-  auto out_off = [&](int a, int y) -> size_t {
-    const int ch = a * 16 + kg * 4;
-    if (POOL) return (((size_t)n * Hh + (y >> 1)) * Wh + (xo >> 1)) * ld + ch;
-    return (((size_t)n * p.H + y) * p.W + xo) * ld + ch;
+  // byte offset of this lane's 4 channels (tile a) at output row y (pooled modes: the half-resolution pixel) in the output / in the
+  // bnr_z tensor, as a 32-bit buffer offset: lanes and rows that must not touch memory get an out-of-range offset, which a buffer load
+  // answers with zeros and a buffer store drops — no branches, no 64-bit address arithmetic per row (r03: the per-row `if (ok)`
+  // blocks with their own v_mad_u64 chains were a quarter of the instructions of the fused data-gradient row; K == 16 TC == ld here)
+  const int Ho = POOL ? Hh : p.H, Wo = POOL ? Wh : p.W;
+  const uint32_t out_bytes = (uint32_t)((size_t)p.N * Ho * Wo * ld * 2);
+  const __amdgpu_buffer_rsrc_t rsy = make_rsrc(p.y0, out_bytes);
+  const __amdgpu_buffer_rsrc_t rsbz = make_rsrc(BNR ? p.bnr_z : p.y0, out_bytes);
+  const bool lane_stores = x_ok && (!POOL || (li & 1) == 0);
+  const uint32_t lane_ob = lane_stores ? (uint32_t)(((n * Ho) * Wo + (POOL ? (xo >> 1) : xo)) * ld + kg * 4) * 2u : kOOB;
+  const uint32_t row_ob = (uint32_t)(Wo * ld * 2);
+  auto out_off = [&](int a, int y) -> uint32_t {           // y < p.H is the caller's business
+    return lane_ob + (uint32_t)(POOL ? (y >> 1) : y) * row_ob + (uint32_t)(a * 32);
   };
   // the z vectors of the fused BN+ReLU-backward reduce are requested one output row (pooled: one row pair) ahead
   u32x2_t zq[2][TC];
   auto z_issue = [&](int y, u32x2_t (&z)[TC]) {
-    const bool ok = x_ok && y < p.H && (!POOL || (li & 1) == 0);
+    const bool ok = y < p.H;
 #pragma unroll
-    for (int a = 0; a < TC; ++a) {
-      z[a] = u32x2_t{0u, 0u};
-      if (ok && a * 16 + kg * 4 < ld) z[a] = *reinterpret_cast<const u32x2_t*>((const char*)p.bnr_z + out_off(a, y) * 2);
-    }
+    for (int a = 0; a < TC; ++a) z[a] = __builtin_amdgcn_raw_buffer_load_b64(rsbz, ok ? out_off(a, y) : kOOB, 0, 0);
   };
   // masks with the BN+ReLU of the layer below, adds the sums, stores 4 channels of one pixel at element offset eoff
-  auto finish = [&](int a, float (&f)[4], u32x2_t pk, size_t eoff, u32x2_t zr) {
+  auto finish = [&](int a, float (&f)[4], u32x2_t pk, uint32_t boff, bool counted, u32x2_t zr) {
     if (BNR) {
       float zf[8];
       Vec16<T>::unpack(u32x4_t{zr[0], zr[1], 0u, 0u}, zf);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (!(fmaf(zf[e], bsc[a][e], bsh[a][e]) > 0.f)) f[e] = 0.f;
+        if (!counted || !(fmaf(zf[e], bsc[a][e], bsh[a][e]) > 0.f)) f[e] = 0.f;      // pixels outside the map add nothing
         s1[a][e] += f[e];
         s2[a][e] += f[e] * zf[e];
       }
       pk = round_t(f);
     } else if (want_sums) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { s1[a][e] += f[e]; s2[a][e] += f[e] * f[e]; }
+      for (int e = 0; e < 4; ++e) {
+        const float v = counted ? f[e] : 0.f;
+        s1[a][e] += v;
+        s2[a][e] += v * v;
+      }
     }
-    *reinterpret_cast<u32x2_t*>((char*)p.y0 + eoff * 2) = pk;
+    __builtin_amdgcn_raw_buffer_store_b64(pk, rsy, boff, 0, 0);
   };
 
   // ---- the row pipeline.  Source row j lives in queue register set j & 3 until it is written to ring slot j & 3; the loop is
@@ -2224,13 +2233,11 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
             const float pn = dpp_f<0xB1>(prev[a][e]), cn = dpp_f<0xB1>(f[e]);      // the odd neighbour column
             t[e] = ((prev[a][e] + pn) + f[e]) + cn;
           }
-          if ((li & 1) == 0 && x_ok && y_ok && ch < ld) {
-            const u32x2_t pk2 = round_t(t);
-            finish(a, t, pk2, out_off(a, y), zq[ZC][a]);
-          }
+          const u32x2_t pk2 = round_t(t);
+          finish(a, t, pk2, y_ok ? out_off(a, y) : kOOB, lane_stores && y_ok, zq[ZC][a]);
         }
-      } else if (x_ok && y_ok && ch < ld) {
-        finish(a, f, pk, out_off(a, y), zq[ZC][a]);
+      } else {
+        finish(a, f, pk, y_ok ? out_off(a, y) : kOOB, lane_stores && y_ok, zq[ZC][a]);
       }
     }
   };
