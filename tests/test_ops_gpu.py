@@ -579,6 +579,72 @@ def test_wgrad_stream_kernel(shape, K, up, dtn, monkeypatch):
     assert (a - tile).abs().max().item() <= 1e-4 * scale          # same operands, fp32 accumulation in another order
 
 
+@pytest.mark.parametrize("dtn", ["bf16", "f16"])
+@pytest.mark.parametrize("workgroups", [3, 7, 16, 256], ids=["wg3", "wg7", "wg16", "wg256"])
+def test_conv_wgrad_batch(workgroups, dtn):
+    """vk_conv_wgrad_batch: the weight gradients of several layers of the 64 x 64 tile class in ONE launch — units (layer, output tile,
+    128-pixel tile) cut into `workgroups` ranges, partial tiles added in range order.  Four layers of different shapes (plain 64 -> 64,
+    128 -> 64 with K tiles, an upsampled + skip concat source, a ragged map) against fp64 autograd and against vk_conv_wgrad layer by
+    layer; few workgroups = many segments per workgroup and ranges that start in the middle of an output tile; twice: same bits."""
+    dt = DT[dtn]
+    lib = L_.lib()
+    layers = [  # N, H, W, sources [(C, up)], K
+        (2, 24, 32, [(64, 0)], 64), (1, 16, 16, [(128, 0)], 128), (2, 16, 16, [(128, 1), (64, 0)], 64), (1, 20, 40, [(64, 0)], 128),
+    ]
+    descs, dzs, dws, refs, keep = [], [], [], [], []
+    for li, (N, H, W, srcs, K) in enumerate(layers):
+        parts, vsrc = [], []
+        for si, (Cc, up) in enumerate(srcs):
+            x = gen(N, Cc, H >> up, W >> up, seed=500 + 10 * li + si)
+            g = torch.Generator().manual_seed(600 + 10 * li + si)
+            sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+            v = rnd(torch.relu(rnd(x, dt) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), dt)
+            if up:
+                v = F.interpolate(v, scale_factor=2, mode="nearest")
+            parts.append(v)
+            xd, scd, shd = to_nhwc(x, dt), D(sc), D(sh)
+            keep.extend([xd, scd, shd])
+            vsrc.append(mk_src(xd, Cc, up, scd, shd, 1))
+        Ctot = sum(c for c, _ in srcs)
+        dz = gen(N, K, H, W, seed=700 + li)
+        wv = torch.zeros(K, Ctot, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(torch.cat(parts, 1).double(), wv, padding=1).backward(rnd(dz, dt).double())
+        refs.append(wv.grad.float())
+        dzd = to_nhwc(dz, dt)
+        keep.append(dzd)
+        d = conv_desc(dt, N, H, W, H, W, K, 3, 1, 1, 0, vsrc[0], vsrc[1] if len(vsrc) > 1 else None)
+        assert lib.vk_conv_wgrad_batch_supports(C.byref(d)) == 1
+        descs.append(d)
+        dzs.append(dzd)
+    n = len(layers)
+    DescArr = L_.vk_conv_desc * n
+    darr = DescArr(*descs)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev())
+    tables = torch.empty(64 << 10, dtype=torch.uint8, device=dev())
+
+    def run_batch():
+        dws = [torch.zeros(l[4], 3, 3, sum(c for c, _ in l[3]), dtype=torch.float32, device=dev()) for l in layers]
+        dzp = (C.c_void_p * n)(*[t_.data_ptr() for t_ in dzs])
+        dwp = (C.c_void_p * n)(*[t_.data_ptr() for t_ in dws])
+        L_.check(lib.vk_conv_wgrad_batch(darr, dzp, dwp, n, workgroups, tables.data_ptr(), tables.numel(), ws.data_ptr(), ws.numel(), st()))
+        torch.cuda.synchronize()
+        return dws
+
+    a, b = run_batch(), run_batch()
+    for li in range(n):
+        assert torch.equal(a[li], b[li])
+        ref = refs[li]
+        scale = ref.abs().max().item() + 1e-6
+        assert (a[li].cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-3 * scale, li
+        single = torch.zeros_like(a[li])
+        L_.check(lib.vk_conv_wgrad(C.byref(descs[li]), dzs[li].data_ptr(), single.data_ptr(), ws.data_ptr(), ws.numel(), st()))
+        torch.cuda.synchronize()
+        assert (a[li] - single).abs().max().item() <= 1e-4 * scale, li
+    # a layer outside the class is refused
+    bad = conv_desc(dt, 1, 16, 16, 16, 16, 32, 3, 1, 1, 0, mk_src(keep[0], 64, 0))
+    assert lib.vk_conv_wgrad_batch_supports(C.byref(bad)) == 0
+
+
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
 def test_conv_wgrad_upsample_concat(dtn, wgrad_path):
     dt = DT[dtn]

@@ -361,6 +361,8 @@ struct Act {                     // a (possibly virtual) activated tensor
 
 using namespace vk;
 
+constexpr int kMaxStages = 16;
+
 struct vk_unet {
   vk_unet_config cfg;
   int eb;                        // element bytes of the activation dtype
@@ -397,6 +399,20 @@ struct vk_unet {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_dirty = false;
+  // weight gradients of the 64 x 64 tile class are collected per backward stage and run as ONE launch (vk_conv_wgrad_batch)
+  struct WItem {
+    vk_conv_desc d;
+    const void* dz;
+    float* dw;
+  };
+  struct WPlan {
+    bool built = false;
+    int target = 0, n = 0;
+    vk::WgradBatchPlan plan;
+  };
+  std::vector<WItem> pending;
+  WPlan wplans[kMaxStages][2];      // [stage][0: every CU, 1: with CUs reserved for a collective]
+  size_t off_tab_wbatch = 0;
   std::vector<PackEntry> pack_tab;
   std::vector<CastRange> cast_tab;
   size_t off_tab_cast = 0;
@@ -605,6 +621,7 @@ void layout_workspace(vk_unet* h) {
   h->off_tab_halo = take(2 * h->convs.size() * sizeof(HaloPackEntry));
   h->off_wstem = take(64 * 7 * 32 * eb);
   h->off_wslab = tr ? take(VK_WGRAD_WORKSPACE_BYTES) : 0;
+  h->off_tab_wbatch = tr ? take((size_t)kMaxStages * 2 * VK_WGRAD_BATCH_TABLE_BYTES) : 0;
   // eval plans with few tiles per layer (batch-1 inference) split the channel reduction: scratch for the partial tiles
   h->splitk_bytes = (!tr && (size_t)N * S * S <= 4u * 512 * 512) ? VK_SPLITK_WORKSPACE_BYTES : 0;
   h->off_splitk = h->splitk_bytes ? take(h->splitk_bytes) : 0;
@@ -795,6 +812,8 @@ extern "C" int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_b
   VK_CHECK_ARG(workspace_bytes >= h->ws_bytes, "vk_unet_bind: workspace too small (%zu < %zu)", workspace_bytes, h->ws_bytes);
   VK_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)params & 15) == 0, "vk_unet_bind: buffers must be 256-byte (workspace) / 16-byte (params) aligned");
   h->params = params; h->grads = grads; h->bufs = bn_buffers; h->nbt = nbt; h->ws = (char*)workspace;
+  for (auto& st_ : h->wplans) { st_[0].built = false; st_[1].built = false; }      // their tables hold the old pointers
+  h->pending.clear();
   assign_pointers(h);
   // device tables
   // which layers run on the 3x3 tile kernels (halo pack weights): ask the kernels' own predicate with the real descriptors
@@ -1045,6 +1064,12 @@ int join_side(vk_unet* h, hipStream_t st) {
 
 int conv_wgrad(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, hipStream_t st) {
   vk_conv_desc d = conv_desc(h, c, s0, s1);
+  // the 64 x 64 tile class waits for the end of its backward stage (flush_wgrads): dz (c.g) and the operands are this layer's own
+  // buffers and stay untouched until the next step
+  if (!h->side && vk::wgrad_batch_supports(&d)) {
+    h->pending.push_back(vk_unet::WItem{d, c.g, h->grads + c.w_off});
+    return VK_OK;
+  }
   hipStream_t ws;
   RET_IF(wgrad_stream(h, st, &ws));
   return vk_conv_wgrad(&d, c.g, h->grads + c.w_off, h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, ws);
@@ -1224,6 +1249,43 @@ int backward_stem(vk_unet* h, hipStream_t st) {
   return vk_stem_wgrad(h->cfg.dtype, N, S, S, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, ws);
 }
 
+// the collected weight gradients of a stage: one batched launch (tables built once per stage and per workgroup budget), a single one
+// through the ordinary entry point
+int flush_wgrads(vk_unet* h, int stage, hipStream_t st) {
+  const int n = (int)h->pending.size();
+  if (n == 0) return VK_OK;
+  char* const slab = h->ws + h->off_wslab;
+  auto each = [&]() {
+    int rc = VK_OK;
+    for (const vk_unet::WItem& it : h->pending) {
+      rc = vk_conv_wgrad(&it.d, it.dz, it.dw, slab, VK_WGRAD_WORKSPACE_BYTES, st);
+      if (rc != VK_OK) break;
+    }
+    h->pending.clear();
+    return rc;
+  };
+  if (n == 1 || n > 16 || stage < 0 || stage >= kMaxStages) return each();
+  const int target = 256 - vkh::reserved_cus();
+  const int slot = target == 256 ? 0 : 1;
+  vk_unet::WPlan& wp = h->wplans[stage][slot];
+  char* const tables = h->ws + h->off_tab_wbatch + ((size_t)stage * 2 + slot) * VK_WGRAD_BATCH_TABLE_BYTES;
+  if (!wp.built || wp.target != target || wp.n != n) {
+    if (wp.built) VK_CHECK_HIP(hipStreamSynchronize(st));          // a launch that reads the old tables may still be in flight
+    vk_conv_desc descs[16];
+    const void* dz[16];
+    float* dw[16];
+    for (int i = 0; i < n; ++i) { descs[i] = h->pending[(size_t)i].d; dz[i] = h->pending[(size_t)i].dz; dw[i] = h->pending[(size_t)i].dw; }
+    wp.plan = vk::WgradBatchPlan();
+    const int rc = vk::wgrad_batch_build(descs, dz, dw, n, target, tables, VK_WGRAD_BATCH_TABLE_BYTES, &wp.plan);
+    if (rc != VK_OK) { h->pending.clear(); return rc; }
+    wp.built = true; wp.target = target; wp.n = n;
+  }
+  if (wp.plan.slab_need > VK_WGRAD_WORKSPACE_BYTES) return each();
+  const int rc = vk::wgrad_batch_launch(h->cfg.dtype, wp.plan, tables, slab, VK_WGRAD_WORKSPACE_BYTES, st);
+  h->pending.clear();
+  return rc;
+}
+
 int backward_stage(vk_unet* h, const float* dlogits, int stage, hipStream_t st) {
   const int N = h->cfg.N, S = h->cfg.size;
   switch (stage) {
@@ -1273,7 +1335,9 @@ extern "C" int vk_unet_backward(vk_unet* h, const float* dlogits, int stage_begi
   VK_CHECK_ARG(h && h->bound && h->cfg.training && h->grads, "vk_unet_backward: needs a bound training plan");
   VK_CHECK_ARG(stage_begin >= 0 && stage_end <= (int)h->buckets.size() && stage_begin <= stage_end, "vk_unet_backward: bad stage range");
   for (int s = stage_begin; s < stage_end; ++s) {
-    const int rc = backward_stage(h, dlogits, s, (hipStream_t)stream);
+    int rc = backward_stage(h, dlogits, s, (hipStream_t)stream);
+    if (rc == VK_OK) rc = flush_wgrads(h, s, (hipStream_t)stream);
+    else h->pending.clear();
     const int rj = join_side(h, (hipStream_t)stream);        // also after a failed stage: never leave the side stream un-joined
     if (rc != VK_OK) return rc;
     if (rj != VK_OK) return rj;

@@ -304,3 +304,17 @@ struct ProfScope {
       return (int)e_;                                                                   \
     }                                                                                   \
   } while (0)
+
+namespace vk {
+// ---------------------------------------------------------------- batched weight gradients (wgrad_halo.hip; used by engine.hip)
+// device table layout inside `tables` (VK_WGRAD_BATCH_TABLE_BYTES): [layers][segments][wg_first][tile reduce entries]
+struct WgradBatchPlan {
+  int nwg = 0, nsegs = 0, ntred = 0, nlayers = 0;
+  size_t off_layers = 0, off_segs = 0, off_wgfirst = 0, off_tred = 0, slab_need = 0;
+  double flops = 0.0, bytes = 0.0;
+};
+bool wgrad_batch_supports(const vk_conv_desc* d);
+int wgrad_batch_build(const vk_conv_desc* descs, const void* const* dz, float* const* dw, int n, int target_blocks, void* tables,
+                      size_t tables_bytes, WgradBatchPlan* plan);
+int wgrad_batch_launch(vk_dtype dt, const WgradBatchPlan& plan, const void* tables, void* slab, size_t slab_bytes, hipStream_t st);
+}  // namespace vk

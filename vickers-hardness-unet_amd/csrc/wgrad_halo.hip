@@ -78,8 +78,13 @@ struct WhCfg {
   static_assert(NSTAGE * STAGE <= 160 * 1024 && RED <= 160 * 1024, "LDS image exceeds the 160 KiB of a CU");
 };
 
+// The body of the kernel for ONE segment of work: output tile (k0, c0) over the pixel tiles t0, t0 + t_step, ... < t_end; the result
+// tile goes to dst[(k * 9 + tap) * ldc + c] (plain stores: a slab or a per-segment partial tile) or, with dst == nullptr, to p.dw by
+// fp32 atomics.  wgrad_halo_kernel runs one segment per workgroup (strided tiles); wgrad_halo_batch_kernel runs the 1-3 segments of
+// a contiguous range of (layer, output tile, pixel tile) units.
 template <typename T, int KT, int CT, bool WS, bool TS, int STR = 1>
-__global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhParams p) {
+__device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const int k0, const int c0, const int t0, const int t_end,
+                                           const int t_step, float* const dst, const int ldc) {
   using Cfg = WhCfg<T, KT, CT, WS, TS, STR>;
   constexpr int HWI = Cfg::HWI, HRS = Cfg::HRS;
   constexpr int NT = Cfg::NT, NTAP = Cfg::NTAP;
@@ -87,12 +92,9 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
   constexpr int ZPASS = Cfg::ZPASS, VPASS = Cfg::VPASS, ZSB = Cfg::ZSB, VSB = Cfg::VSB, STAGE = Cfg::STAGE;
   constexpr int TK = Cfg::TK, TCc = Cfg::TCc;
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
   const int half = __builtin_amdgcn_readfirstlane(tid >> 8);   // tap group (TS); wave-uniform by construction
-  const int k0 = blockIdx.x * KT;
-  const int c0 = blockIdx.y * CT;                 // channel in concat space
-  const bool first = c0 < p.s0.C;
+  const bool first = c0 < p.s0.C;                 // c0: channel in concat space
   const WhSrc& sd = first ? p.s0 : p.s1;
   const int cl0 = first ? c0 : c0 - p.s0.C;
   const __amdgpu_buffer_rsrc_t rsv = make_rsrc(sd.ptr, sd.bytes);
@@ -347,20 +349,20 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
 
   // ---- stream over this workgroup's pixel tiles: t = blockIdx.z, + splits, ...
   const int dbg = p.dbg_skip_epilogue >> 1;     // timing experiments (VK_WH_DBG, results WRONG): 1 no tile loads, 2 no LDS tile stores, 4 no MFMA steps, 8 no barriers
-  int t = blockIdx.z;
-  if (t < p.ntiles) {
+  int t = t0;
+  if (t < t_end) {
     load_tile(t, zreg[0], vreg[0], vmask[0]);
     store_tile(0, zreg[0], vreg[0], vmask[0]);
   }
-  if (DEPTH == 2 && t + p.splits < p.ntiles) load_tile(t + p.splits, zreg[0], vreg[0], vmask[0]);     // tile 1 -> set 0
+  if (DEPTH == 2 && t + t_step < t_end) load_tile(t + t_step, zreg[0], vreg[0], vmask[0]);     // tile 1 -> set 0
   __syncthreads();
   auto tile_loop = [&](auto hsel_c) {
     auto iteration = [&](int it, u32x4_t (&zl)[ZPASS], u32x4_t (&vl)[VPASS], uint32_t& ml, const u32x4_t (&zs)[ZPASS],
                          const u32x4_t (&vs)[VPASS], const uint32_t& ms) {
       // loads go into set (zl, vl); the set (zs, vs) — requested one (DEPTH 2) or zero (DEPTH 1: same set) iterations ago — is stored
-      const bool more = t + p.splits < p.ntiles;
-      const int tl = t + DEPTH * p.splits;
-      if (tl < p.ntiles && !(dbg & 1)) load_tile(tl, zl, vl, ml);
+      const bool more = t + t_step < t_end;
+      const int tl = t + DEPTH * t_step;
+      if (tl < t_end && !(dbg & 1)) load_tile(tl, zl, vl, ml);
       const char* Zs = smem + (it & 1) * STAGE;
       const char* Vs = Zs + PX * ZSB;
       bool stored = false;
@@ -384,15 +386,15 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
       if (!stored && more && !(dbg & 2)) store_tile((it + 1) & 1, zs, vs, ms);
       if (!(dbg & 8)) __syncthreads();
     };
-    for (int it = 0; t < p.ntiles; t += p.splits, ++it) {
+    for (int it = 0; t < t_end; t += t_step, ++it) {
       if (DEPTH == 1) {
         iteration(it, zreg[0], vreg[0], vmask[0], zreg[0], vreg[0], vmask[0]);
       } else {
         // even iterations: tile t+2 -> set 1, tile t+1 (set 0) -> LDS; odd iterations the other way round
         iteration(it, zreg[DEPTH - 1], vreg[DEPTH - 1], vmask[DEPTH - 1], zreg[0], vreg[0], vmask[0]);
-        t += p.splits;
+        t += t_step;
         ++it;
-        if (t >= p.ntiles) break;
+        if (t >= t_end) break;
         iteration(it, zreg[0], vreg[0], vmask[0], zreg[DEPTH - 1], vreg[DEPTH - 1], vmask[DEPTH - 1]);
       }
     }
@@ -434,19 +436,77 @@ __global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhPara
     __syncthreads();
   }
   constexpr int C4 = CT / 4;
-  float* const slab = p.slab ? p.slab + (size_t)blockIdx.z * p.K * 9 * p.C : nullptr;
   for (int i = tid; i < KT * 9 * C4; i += NT) {
     const int row = i / C4, c4 = i - row * C4;
     const int k = row / 9, tp = row - k * 9;
     if (k0 + k >= p.K) continue;
     const f32x4_t v = *reinterpret_cast<const f32x4_t*>(red + row * CT + c4 * 4);
-    const size_t off = ((size_t)(k0 + k) * 9 + tp) * p.C + c0 + c4 * 4;
-    if (slab) {
-      *reinterpret_cast<f32x4_t*>(slab + off) = v;
+    if (dst) {
+      *reinterpret_cast<f32x4_t*>(dst + (size_t)row * ldc + c4 * 4) = v;
     } else {
+      const size_t off = ((size_t)(k0 + k) * 9 + tp) * p.C + c0 + c4 * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) atomicAdd(p.dw + off + e, v[e]);
     }
+  }
+}
+
+template <typename T, int KT, int CT, bool WS, bool TS, int STR = 1>
+__global__ __launch_bounds__(TS ? 512 : 256) void wgrad_halo_kernel(const WhParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k0 = blockIdx.x * KT, c0 = blockIdx.y * CT;
+  // slab mode: this split's slab in the layout of dw ([K][9][C]); the tile starts at row k0 * 9, column c0
+  float* const dst = p.slab ? p.slab + (size_t)blockIdx.z * p.K * 9 * p.C + (size_t)k0 * 9 * p.C + c0 : nullptr;
+  wh_segment<T, KT, CT, WS, TS, STR>(p, smem, k0, c0, (int)blockIdx.z, p.ntiles, p.splits, dst, p.C);
+}
+
+// ---- one launch for SEVERAL layers of the 64 x 64 tap-split class (r03): the units (layer, output tile, 128-pixel tile) of all of them in
+// one line, cut into equal ranges, one per workgroup; a range that crosses an output-tile boundary becomes two (three) segments, each
+// leaving a partial tile [64][9][64]; k_wgrad_tile_reduce adds the partial tiles of every output tile in range order (reproducible).
+// Why: a single layer's launch is 16 tiles of work per workgroup against ~11 us of fixed cost, a 7 us epilogue, 37.7 MB of slabs and a
+// 9.5 us reduce launch (profiles/r03/wgrad_layout_experiments.log); batching the 2-7 layers of a backward stage pays those once.
+struct WhSeg {
+  int layer, k0, c0, t0, t1, slot;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad_halo_batch_kernel(const WhParams* __restrict__ layers, const WhSeg* __restrict__ segs,
+                                                               const int* __restrict__ wg_first, float* slab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int s0 = wg_first[blockIdx.x], s1 = wg_first[blockIdx.x + 1];
+  for (int s_ = s0; s_ < s1; ++s_) {
+    const WhSeg sg = segs[s_];
+    const WhParams p = layers[sg.layer];
+    wh_segment<T, 64, 64, false, true, 1>(p, smem, sg.k0, sg.c0, sg.t0, sg.t1, 1, slab + (size_t)sg.slot * (64 * 9 * 64), 64);
+    __syncthreads();                                // the epilogue's LDS tile is read out before the next segment stages into it
+  }
+}
+
+// dw tile (k0, c0) of one layer += its partial tiles first .. first + n - 1, in that order
+struct WhTileRed {
+  float* dw;            // dw + k0 * 9 * C + c0
+  int ldc, first, n, krows;
+};
+__global__ __launch_bounds__(256) void k_wgrad_tile_reduce(const WhTileRed* __restrict__ tab, const float* __restrict__ slab) {
+  const WhTileRed tr = tab[blockIdx.x];
+  // 64 x 9 rows of 16 float4: blockIdx.y takes 64 rows; thread = (row, float4)
+  const int row = (int)blockIdx.y * 16 + (threadIdx.x >> 4), c4 = threadIdx.x & 15;
+#pragma unroll 1
+  for (int rr = row; rr < 64 * 9; rr += 16 * (int)gridDim.y) {
+    if (rr / 9 >= tr.krows) continue;
+    const float* src = slab + (size_t)tr.first * (64 * 9 * 64) + (size_t)rr * 64 + c4 * 4;
+    f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; i + 4 <= tr.n; i += 4) {                  // four loads in flight, added in order
+      const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src + (size_t)i * (64 * 9 * 64));
+      const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(src + (size_t)(i + 1) * (64 * 9 * 64));
+      const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(src + (size_t)(i + 2) * (64 * 9 * 64));
+      const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(src + (size_t)(i + 3) * (64 * 9 * 64));
+      a = a + v0; a = a + v1; a = a + v2; a = a + v3;
+    }
+    for (; i < tr.n; ++i) a = a + *reinterpret_cast<const f32x4_t*>(src + (size_t)i * (64 * 9 * 64));
+    float* d = tr.dw + (size_t)rr * tr.ldc + c4 * 4;
+    *reinterpret_cast<f32x4_t*>(d) = *reinterpret_cast<const f32x4_t*>(d) + a;
   }
 }
 
@@ -920,14 +980,9 @@ static int wh_select(const WhParams& p, int cgran, size_t slab_bytes, hipStream_
   return VK_ERR_UNSUPPORTED;
 }
 
-// returns VK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the tap-by-tap kernel)
-int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, void* workspace, size_t workspace_bytes, hipStream_t st) {
-  // stride 2 (16-bit types): the openers of layers 2-4 — materialised single source, reduction chunks of 32 channels
-  const bool s2 = d->stride == 2 && d->dtype != VK_F32 && d->H == 2 * d->Ho && d->W == 2 * d->Wo && !d->src1.ptr && !d->src0.up && d->src0.C % 32 == 0 &&
-                  d->K >= 64 && !getenv("VK_NO_S2_TILE");
-  if (d->R != 3 || d->S != 3 || d->pad != 1) return VK_ERR_UNSUPPORTED;
-  if (!s2 && (d->stride != 1 || d->H != d->Ho || d->W != d->Wo)) return VK_ERR_UNSUPPORTED;
-  if (getenv("VK_NO_WGRAD_HALO")) return VK_ERR_UNSUPPORTED;
+// descriptor -> kernel parameters (shared by the single-layer and the batched launch); *cgran: channel granularity that keeps a
+// c-tile inside one concat source
+static int make_wh_params(const vk_conv_desc* d, const void* dz, float* dw, WhParams* out, int* cgran_out) {
   const int eb = d->dtype == VK_F32 ? 4 : 2;
   const int C = d->src0.C + (d->src1.ptr ? d->src1.C : 0);
   if (d->K % 16 || d->src0.C % 16 || (d->src1.ptr && (d->src1.C % 16 || d->src1.up))) return VK_ERR_UNSUPPORTED;
@@ -951,6 +1006,26 @@ int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, void* works
   p.Hi = d->H; p.Wi = d->W;
   p.tiles_x = p.tiles_y = p.ntiles = p.splits = 0;
   p.dbg_skip_epilogue = 0;
+  p.slab = nullptr;
+  *out = p;
+  *cgran_out = cgran;
+  return VK_OK;
+}
+
+// returns VK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the tap-by-tap kernel)
+int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  // stride 2 (16-bit types): the openers of layers 2-4 — materialised single source, reduction chunks of 32 channels
+  const bool s2 = d->stride == 2 && d->dtype != VK_F32 && d->H == 2 * d->Ho && d->W == 2 * d->Wo && !d->src1.ptr && !d->src0.up && d->src0.C % 32 == 0 &&
+                  d->K >= 64 && !getenv("VK_NO_S2_TILE");
+  if (d->R != 3 || d->S != 3 || d->pad != 1) return VK_ERR_UNSUPPORTED;
+  if (!s2 && (d->stride != 1 || d->H != d->Ho || d->W != d->Wo)) return VK_ERR_UNSUPPORTED;
+  if (getenv("VK_NO_WGRAD_HALO")) return VK_ERR_UNSUPPORTED;
+  WhParams p;
+  int cgran = 64;
+  {
+    const int rc = make_wh_params(d, dz, dw, &p, &cgran);
+    if (rc != VK_OK) return rc;
+  }
   p.slab = (float*)workspace;
   if (s2) {
     if (d->dtype == VK_BF16) return launch_wh<bf16_t, 64, 32, false, true, 2>(p, workspace_bytes, st);
@@ -964,4 +1039,150 @@ int wgrad_halo_try(const vk_conv_desc* d, const void* dz, float* dw, void* works
   return VK_ERR_ARG;
 }
 
+// ------------------------------------------------------------------------------------------------ batched launch (see wgrad_halo_batch_kernel)
+// would wgrad_halo_try run this layer on the 64 x 64 tap-split tile kernel (16-bit, 3x3 stride 1, K >= 64, every source a multiple of
+// 64 channels)?  Those are the layers a batch may hold.
+bool wgrad_batch_supports(const vk_conv_desc* d) {
+  if (d->dtype == VK_F32 || d->R != 3 || d->S != 3 || d->pad != 1 || d->stride != 1 || d->H != d->Ho || d->W != d->Wo) return false;
+  if (getenv("VK_NO_WGRAD_HALO") || getenv("VK_WH_NO_TS") || getenv("VK_WH_NO_SLAB") || getenv("VK_NO_WGRAD_BATCH")) return false;
+  WhParams p;
+  int cgran;
+  if (make_wh_params(d, d->src0.ptr, nullptr, &p, &cgran) != VK_OK) return false;
+  if (p.K < 64 || cgran % 64) return false;
+  const int kt = (p.K + 63) / 64, ct = p.C / 64;
+  return kt * ct <= wh_max_combo();
+}
+
+
+// Builds the tables of one batch on the host, copies them into `tables` (synchronous copy: called once per stage and plan) and
+// returns the plan.  target_blocks: workgroups of the launch (one per CU that may be used).
+int wgrad_batch_build(const vk_conv_desc* descs, const void* const* dz, float* const* dw, int n, int target_blocks, void* tables,
+                      size_t tables_bytes, WgradBatchPlan* plan) {
+  VK_CHECK_ARG(n >= 1 && n <= 16 && target_blocks >= 1, "wgrad batch: %d layers, %d workgroups", n, target_blocks);
+  std::vector<WhParams> layers((size_t)n);
+  long total_units = 0;
+  std::vector<int> kt((size_t)n), ct((size_t)n);
+  for (int l = 0; l < n; ++l) {
+    int cgran;
+    const int rc = make_wh_params(&descs[l], dz[l], dw[l], &layers[(size_t)l], &cgran);
+    if (rc != VK_OK) return rc;
+    WhParams& q = layers[(size_t)l];
+    q.tiles_x = (q.W + 15) / 16;
+    q.tiles_y = (q.H + 7) / 8;
+    q.ntiles = q.N * q.tiles_y * q.tiles_x;
+    q.splits = 1;
+    kt[(size_t)l] = (q.K + 63) / 64;
+    ct[(size_t)l] = q.C / 64;
+    total_units += (long)kt[(size_t)l] * ct[(size_t)l] * q.ntiles;
+    plan->flops += 2.0 * (double)q.N * q.H * q.W * q.K * 9.0 * q.C;
+    plan->bytes += ((double)q.N * q.Hi * q.Wi * q.C + (double)q.N * q.H * q.W * q.K) * 2.0 + 9.0 * q.K * q.C * 4.0;
+  }
+  const int nwg = target_blocks;
+  const long chunk = (total_units + nwg - 1) / nwg;
+  constexpr long MINSEG = 4;                              // a segment pays a full epilogue (~3 units of work): no crumbs
+  std::vector<WhSeg> segs;
+  std::vector<int> wg_first;
+  std::vector<WhTileRed> tred;
+  int wg = 0;
+  long room = chunk;
+  wg_first.push_back(0);
+  auto next_wg = [&]() {
+    if (wg + 1 < nwg) {
+      ++wg;
+      wg_first.push_back((int)segs.size());
+      room = chunk;
+    } else {
+      room = 1L << 40;                                   // the last workgroup takes whatever is left
+    }
+  };
+  for (int l = 0; l < n; ++l) {
+    const WhParams& q = layers[(size_t)l];
+    for (int ki = 0; ki < kt[(size_t)l]; ++ki)
+      for (int ci = 0; ci < ct[(size_t)l]; ++ci) {
+        WhTileRed tr;
+        tr.dw = q.dw + (size_t)ki * 64 * 9 * q.C + (size_t)ci * 64;
+        tr.ldc = q.C;
+        tr.first = (int)segs.size();
+        tr.krows = q.K - ki * 64 < 64 ? q.K - ki * 64 : 64;
+        int t = 0;
+        while (t < q.ntiles) {
+          long left = q.ntiles - t;
+          if (room < MINSEG && wg_first.back() != (int)segs.size()) next_wg();       // do not start a crumb at the end of a range
+          long m = left < room ? left : room;
+          if (left - m < MINSEG) m = left;                                           // do not leave a crumb behind
+          segs.push_back(WhSeg{l, ki * 64, ci * 64, t, (int)(t + m), (int)segs.size()});
+          t += (int)m;
+          room -= m;
+          if (room <= 0) next_wg();
+        }
+        tr.n = (int)segs.size() - tr.first;
+        tred.push_back(tr);
+      }
+  }
+  while ((int)wg_first.size() < nwg + 1) wg_first.push_back((int)segs.size());      // workgroups without work (tiny problems)
+  wg_first[(size_t)nwg] = (int)segs.size();
+  plan->nwg = nwg; plan->nsegs = (int)segs.size(); plan->ntred = (int)tred.size(); plan->nlayers = n;
+  size_t off = 0;
+  auto take = [&](size_t b) { const size_t o = off; off = (off + b + 255) & ~(size_t)255; return o; };
+  plan->off_layers = take(layers.size() * sizeof(WhParams));
+  plan->off_segs = take(segs.size() * sizeof(WhSeg));
+  plan->off_wgfirst = take(wg_first.size() * sizeof(int));
+  plan->off_tred = take(tred.size() * sizeof(WhTileRed));
+  VK_CHECK_ARG(off <= tables_bytes, "wgrad batch: tables need %zu bytes, %zu given", off, tables_bytes);
+  plan->slab_need = segs.size() * (size_t)(64 * 9 * 64) * sizeof(float);
+  char* tb = (char*)tables;
+  VK_CHECK_HIP(hipMemcpy(tb + plan->off_layers, layers.data(), layers.size() * sizeof(WhParams), hipMemcpyHostToDevice));
+  VK_CHECK_HIP(hipMemcpy(tb + plan->off_segs, segs.data(), segs.size() * sizeof(WhSeg), hipMemcpyHostToDevice));
+  VK_CHECK_HIP(hipMemcpy(tb + plan->off_wgfirst, wg_first.data(), wg_first.size() * sizeof(int), hipMemcpyHostToDevice));
+  VK_CHECK_HIP(hipMemcpy(tb + plan->off_tred, tred.data(), tred.size() * sizeof(WhTileRed), hipMemcpyHostToDevice));
+  return VK_OK;
+}
+
+int wgrad_batch_launch(vk_dtype dt, const WgradBatchPlan& plan, const void* tables, void* slab, size_t slab_bytes, hipStream_t st) {
+  VK_CHECK_ARG(dt != VK_F32 && plan.nwg > 0 && slab && plan.slab_need <= slab_bytes, "wgrad batch: slab of %zu bytes needed, %zu given",
+               plan.slab_need, slab_bytes);
+  using Cfg = WhCfg<bf16_t, 64, 64, false, true, 1>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_halo_batch_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+    VK_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_halo_batch_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+    attr_done = true;
+  }
+  const char* tb = (const char*)tables;
+  {
+    vkh::ProfScope ps("wgrad_halo_16b_64x64ts_batch", st, plan.flops, plan.bytes);
+    if (dt == VK_BF16)
+      hipLaunchKernelGGL(wgrad_halo_batch_kernel<bf16_t>, dim3((unsigned)plan.nwg), dim3(512), Cfg::SMEM, st, (const WhParams*)(tb + plan.off_layers),
+                         (const WhSeg*)(tb + plan.off_segs), (const int*)(tb + plan.off_wgfirst), (float*)slab);
+    else
+      hipLaunchKernelGGL(wgrad_halo_batch_kernel<f16_t>, dim3((unsigned)plan.nwg), dim3(512), Cfg::SMEM, st, (const WhParams*)(tb + plan.off_layers),
+                         (const WhSeg*)(tb + plan.off_segs), (const int*)(tb + plan.off_wgfirst), (float*)slab);
+  }
+  {
+    vkh::ProfScope ps("wgrad_slab_reduce", st, 0.0, (double)plan.slab_need + 2.0 * plan.ntred * 64.0 * 9.0 * 64.0 * 4.0);
+    hipLaunchKernelGGL(k_wgrad_tile_reduce, dim3((unsigned)plan.ntred, 4), dim3(256), 0, st, (const WhTileRed*)(tb + plan.off_tred), (const float*)slab);
+  }
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
+}
+
+}  // namespace vk
+
+// C ABI: weight gradients of n layers (every one must satisfy vk_conv_wgrad_batch_supports) in one launch.  `tables`: device scratch of
+// VK_WGRAD_BATCH_TABLE_BYTES that the call fills (synchronously) before it launches; `workspace`: the slab workspace of vk_conv_wgrad.
+extern "C" int vk_conv_wgrad_batch_supports(const vk_conv_desc* d) { return d && vk::wgrad_batch_supports(d) ? 1 : 0; }
+extern "C" int vk_conv_wgrad_batch(const vk_conv_desc* descs, const void* const* dz, float* const* dw, int n, int workgroups, void* tables,
+                                   size_t tables_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+  VK_CHECK_ARG(descs && dz && dw && tables && workspace, "vk_conv_wgrad_batch: null argument");
+  for (int l = 0; l < n; ++l) {
+    VK_CHECK_ARG(vk::wgrad_batch_supports(&descs[l]), "vk_conv_wgrad_batch: layer %d is not of the batched class", l);
+    VK_CHECK_ARG(descs[l].dtype == descs[0].dtype, "vk_conv_wgrad_batch: mixed element types");
+  }
+  vk::WgradBatchPlan plan;
+  const int rc = vk::wgrad_batch_build(descs, dz, dw, n, workgroups > 0 ? workgroups : 256 - vkh::reserved_cus(), tables, tables_bytes, &plan);
+  if (rc != VK_OK) return rc;
+  return vk::wgrad_batch_launch(descs[0].dtype, plan, tables, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+namespace vk {
 }  // namespace vk
