@@ -620,7 +620,7 @@ def test_conv_wgrad_batch(workgroups, dtn):
     DescArr = L_.vk_conv_desc * n
     darr = DescArr(*descs)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev())
-    tables = torch.empty(64 << 10, dtype=torch.uint8, device=dev())
+    tables = torch.empty(128 << 10, dtype=torch.uint8, device=dev())
 
     def run_batch():
         dws = [torch.zeros(l[4], 3, 3, sum(c for c, _ in l[3]), dtype=torch.float32, device=dev()) for l in layers]

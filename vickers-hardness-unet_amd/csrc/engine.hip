@@ -362,6 +362,8 @@ struct Act {                     // a (possibly virtual) activated tensor
 using namespace vk;
 
 constexpr int kMaxStages = 16;
+constexpr int kMaxBatch = 40;                       // layers in one batched weight-gradient launch (the model has 35 of the class)
+constexpr size_t kEngineSlabBytes = 176u << 20;     // slab workspace of a training plan: partial tiles of a whole-backward batch (~950 x 147 KB)
 
 struct vk_unet {
   vk_unet_config cfg;
@@ -620,7 +622,7 @@ void layout_workspace(vk_unet* h) {
   h->off_wh = take((size_t)h->n_params * eb);                  // halo packs of the forward weights (same offsets as the flat copy)
   h->off_tab_halo = take(2 * h->convs.size() * sizeof(HaloPackEntry));
   h->off_wstem = take(64 * 7 * 32 * eb);
-  h->off_wslab = tr ? take(VK_WGRAD_WORKSPACE_BYTES) : 0;
+  h->off_wslab = tr ? take(kEngineSlabBytes) : 0;
   h->off_tab_wbatch = tr ? take((size_t)kMaxStages * 2 * VK_WGRAD_BATCH_TABLE_BYTES) : 0;
   // eval plans with few tiles per layer (batch-1 inference) split the channel reduction: scratch for the partial tiles
   h->splitk_bytes = (!tr && (size_t)N * S * S <= 4u * 512 * 512) ? VK_SPLITK_WORKSPACE_BYTES : 0;
@@ -1258,30 +1260,30 @@ int flush_wgrads(vk_unet* h, int stage, hipStream_t st) {
   auto each = [&]() {
     int rc = VK_OK;
     for (const vk_unet::WItem& it : h->pending) {
-      rc = vk_conv_wgrad(&it.d, it.dz, it.dw, slab, VK_WGRAD_WORKSPACE_BYTES, st);
+      rc = vk_conv_wgrad(&it.d, it.dz, it.dw, slab, kEngineSlabBytes, st);
       if (rc != VK_OK) break;
     }
     h->pending.clear();
     return rc;
   };
-  if (n == 1 || n > 16 || stage < 0 || stage >= kMaxStages) return each();
+  if (n == 1 || n > kMaxBatch || stage < 0 || stage >= kMaxStages) return each();
   const int target = 256 - vkh::reserved_cus();
   const int slot = target == 256 ? 0 : 1;
   vk_unet::WPlan& wp = h->wplans[stage][slot];
   char* const tables = h->ws + h->off_tab_wbatch + ((size_t)stage * 2 + slot) * VK_WGRAD_BATCH_TABLE_BYTES;
   if (!wp.built || wp.target != target || wp.n != n) {
     if (wp.built) VK_CHECK_HIP(hipStreamSynchronize(st));          // a launch that reads the old tables may still be in flight
-    vk_conv_desc descs[16];
-    const void* dz[16];
-    float* dw[16];
+    vk_conv_desc descs[kMaxBatch];
+    const void* dz[kMaxBatch];
+    float* dw[kMaxBatch];
     for (int i = 0; i < n; ++i) { descs[i] = h->pending[(size_t)i].d; dz[i] = h->pending[(size_t)i].dz; dw[i] = h->pending[(size_t)i].dw; }
     wp.plan = vk::WgradBatchPlan();
     const int rc = vk::wgrad_batch_build(descs, dz, dw, n, target, tables, VK_WGRAD_BATCH_TABLE_BYTES, &wp.plan);
     if (rc != VK_OK) { h->pending.clear(); return rc; }
     wp.built = true; wp.target = target; wp.n = n;
   }
-  if (wp.plan.slab_need > VK_WGRAD_WORKSPACE_BYTES) return each();
-  const int rc = vk::wgrad_batch_launch(h->cfg.dtype, wp.plan, tables, slab, VK_WGRAD_WORKSPACE_BYTES, st);
+  if (wp.plan.slab_need > kEngineSlabBytes) return each();
+  const int rc = vk::wgrad_batch_launch(h->cfg.dtype, wp.plan, tables, slab, kEngineSlabBytes, st);
   h->pending.clear();
   return rc;
 }
@@ -1336,8 +1338,10 @@ extern "C" int vk_unet_backward(vk_unet* h, const float* dlogits, int stage_begi
   VK_CHECK_ARG(stage_begin >= 0 && stage_end <= (int)h->buckets.size() && stage_begin <= stage_end, "vk_unet_backward: bad stage range");
   for (int s = stage_begin; s < stage_end; ++s) {
     int rc = backward_stage(h, dlogits, s, (hipStream_t)stream);
-    if (rc == VK_OK) rc = flush_wgrads(h, s, (hipStream_t)stream);
-    else h->pending.clear();
+    // the collected weight gradients run at the end of the CALL (every stage of the range in one batch) — a caller that needs a
+    // stage's gradients early (the data-parallel reducer: one call per stage) gets them per stage
+    if (rc == VK_OK && (s + 1 == stage_end || (int)h->pending.size() > kMaxBatch - 8)) rc = flush_wgrads(h, s, (hipStream_t)stream);
+    else if (rc != VK_OK) h->pending.clear();
     const int rj = join_side(h, (hipStream_t)stream);        // also after a failed stage: never leave the side stream un-joined
     if (rc != VK_OK) return rc;
     if (rj != VK_OK) return rj;

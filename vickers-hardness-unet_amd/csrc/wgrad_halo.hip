@@ -1058,7 +1058,7 @@ bool wgrad_batch_supports(const vk_conv_desc* d) {
 // returns the plan.  target_blocks: workgroups of the launch (one per CU that may be used).
 int wgrad_batch_build(const vk_conv_desc* descs, const void* const* dz, float* const* dw, int n, int target_blocks, void* tables,
                       size_t tables_bytes, WgradBatchPlan* plan) {
-  VK_CHECK_ARG(n >= 1 && n <= 16 && target_blocks >= 1, "wgrad batch: %d layers, %d workgroups", n, target_blocks);
+  VK_CHECK_ARG(n >= 1 && n <= 40 && target_blocks >= 1, "wgrad batch: %d layers (1..40), %d workgroups", n, target_blocks);
   std::vector<WhParams> layers((size_t)n);
   long total_units = 0;
   std::vector<int> kt((size_t)n), ct((size_t)n);

@@ -13,6 +13,7 @@ There is no CPU execution path: a CPU tensor or a missing libvkunet.so raises.
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 import math
 from typing import Dict, List, Optional, Tuple
@@ -335,6 +336,10 @@ class Unet(nn.Module):
             check(L.vk_unet_set_side_stream(plan.h, 0), "vk_unet_set_side_stream")    # see include/vk_unet.h
             plan._side_off = True
         capped = False
+        if red is None and not os.environ.get("VK_BACKWARD_PER_STAGE"):
+            # nobody needs a stage's gradients before the end: one call, so that the weight gradients of ALL stages run as one batch
+            check(L.vk_unet_backward(plan.h, _lib.ptr(dlogits), 0, plan.nbuckets, st), "vk_unet_backward")
+            return
         try:
             for s in range(plan.nbuckets):
                 if red is not None and red.reserved_cus > 0 and red.in_flight and not capped:
