@@ -141,3 +141,26 @@ def test_engine_bucket_table(vk):
         assert sizes[-1] < 300_000 and all(3_500_000 < s < 5_000_000 for s in sizes[3:6])
     finally:
         L.vk_unet_destroy(h)
+
+
+def test_reducer_stage_groups(vk):
+    """Which backward stages may run as ONE vk_unet_backward call (= one weight-gradient batch): exactly those whose gradients the
+    policy does not look at before the last of them has finished."""
+    flat = torch.zeros(16)
+
+    def groups(**kw):
+        r = vk.GradientReducer(lambda: flat, world_size=2, **kw)
+        r.enabled = True           # no process group in this test: only the grouping logic is asked
+        return r.stage_groups(10)
+
+    assert groups(policy="eager") == [(s, s + 1) for s in range(10)]
+    assert groups(policy="deferred", defer_until=9) == [(0, 9), (9, 10)]
+    assert groups(policy="deferred", defer_until=4) == [(0, 4)] + [(s, s + 1) for s in range(4, 10)]
+    assert groups(policy="deferred", defer_until=0) == [(s, s + 1) for s in range(10)]
+    assert groups(policy="deferred", defer_until=99) == [(0, 10)]
+    assert groups(policy="tail") == [(0, 10)]
+    r = vk.GradientReducer(lambda: flat, world_size=1)
+    assert r.stage_groups(10) == [(0, 10)]          # a disabled reducer (one rank) needs nothing early
+    # the groups cover every stage once, in order
+    for g in (groups(policy="eager"), groups(policy="deferred", defer_until=7), groups(policy="tail")):
+        assert [s for a, b in g for s in range(a, b)] == list(range(10))

@@ -81,6 +81,17 @@ class GradientReducer:
             self._issue(b0, b1)
         self._held.clear()
 
+    def stage_groups(self, nbuckets: int) -> List[Tuple[int, int]]:
+        """Backward stages whose gradients are first needed TOGETHER, as [begin, end) ranges: the model runs each range as one
+        ``vk_unet_backward`` call, i.e. one weight-gradient batch (include/vk_unet.h, vk_conv_wgrad_batch).  "eager" needs every
+        stage at once, "deferred" nothing before stage ``defer_until - 1`` is done, "tail" nothing before the end."""
+        if not self.enabled or self.policy == "tail":
+            return [(0, nbuckets)]
+        if self.policy == "deferred":
+            first = max(1, min(self.defer_until, nbuckets))
+            return [(0, first)] + [(s, s + 1) for s in range(first, nbuckets)]
+        return [(s, s + 1) for s in range(nbuckets)]
+
     def bucket_ready(self, index: int, rng: Tuple[int, int]):
         if not self.enabled:
             return

@@ -340,14 +340,17 @@ class Unet(nn.Module):
             # nobody needs a stage's gradients before the end: one call, so that the weight gradients of ALL stages run as one batch
             check(L.vk_unet_backward(plan.h, _lib.ptr(dlogits), 0, plan.nbuckets, st), "vk_unet_backward")
             return
+        groups = red.stage_groups(plan.nbuckets) if hasattr(red, "stage_groups") and not os.environ.get("VK_BACKWARD_PER_STAGE") \
+            else [(s, s + 1) for s in range(plan.nbuckets)]
         try:
-            for s in range(plan.nbuckets):
+            for s0, s1 in groups:
                 if red is not None and red.reserved_cus > 0 and red.in_flight and not capped:
                     L.vk_set_reserved_cus(red.reserved_cus)      # collectives share the chip from here on: see parallel.py
                     capped = True
-                check(L.vk_unet_backward(plan.h, _lib.ptr(dlogits), s, s + 1, st), "vk_unet_backward")
+                check(L.vk_unet_backward(plan.h, _lib.ptr(dlogits), s0, s1, st), "vk_unet_backward")
                 if red is not None:
-                    red.bucket_ready(s, plan.buckets[s])
+                    for s in range(s0, s1):
+                        red.bucket_ready(s, plan.buckets[s])
         finally:
             if capped:
                 L.vk_set_reserved_cus(0)
