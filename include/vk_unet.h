@@ -358,6 +358,14 @@ int vk_upsample2x_bwd(vk_dtype dtype, int N, int H, int W, int C, const void* d_
 /* Segmentation head: 3x3 pad-1 conv C=16 -> 1 with bias on the activated decoder output; fp32 logits. */
 int vk_head_fwd(vk_dtype dtype, int N, int H, int W, const vk_src* src, const float* w9x16, const float* bias,
                 float* logits, void* stream);
+/* Inference only, 16-bit element types (r03): decoder block 4 conv1 -> BN+ReLU -> conv2 -> BN+ReLU -> head over one overlapping tile —
+ * smp's DecoderBlock + SegmentationHead behind `model(x)` in eval mode (infer_pth_gui.py:45-53) without the two 512^2 x 16 tensors
+ * between them going through HBM.  src: the 32-channel output of decoder block 3 (raw z + its BatchNorm affine, up = 1); w1_pack: conv1
+ * weights as vk_halo_pack(16 rows, 32 channels); w2_plain: conv2 weights [16][3][3][16] of the element type; scale / shift: the folded
+ * eval BatchNorm affines; head as in vk_head_fwd.  H, W multiples of 16.  Same bits as the three separate calls. */
+int vk_dec4_tail_eval(vk_dtype dtype, int N, int H, int W, const vk_src* src, const void* w1_pack, const float* scale1, const float* shift1,
+                      const void* w2_plain, const float* scale2, const float* shift2, const float* head_w9x16, const float* head_bias,
+                      float* logits, void* stream);
 /* workspace (optional, VK_HEAD_WORKSPACE_BYTES is always enough): per-workgroup partial weight gradients that a second launch
  * adds in workgroup order -> dw / dbias are bit-reproducible; NULL: fp32 atomics */
 #define VK_HEAD_WORKSPACE_BYTES (1024u * 148u * 4u)

@@ -567,3 +567,39 @@ def test_config5_fp16_train_bs8_1024_properties_and_eval_logits():
         opt.step(grad_scale=scale_t)
     assert losses[-1] < losses[0]
     assert opt.step_count == 4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("n,s", [(2, 64), (1, 160), (3, 96)])
+def test_eval_decoder_tail_fusion_matches_separate_launches(monkeypatch, dtype, n, s):
+    """Inference in the 16-bit types runs decoder block 4 + the head as ONE kernel (vk_dec4_tail_eval: conv1 -> BN+ReLU -> conv2 ->
+    BN+ReLU -> head over an overlapping tile; the two 512^2 x 16 tensors never reach HBM).  Same operand order per accumulator as the
+    three kernels it replaces, so the logits must be the SAME BITS as with VK_NO_TAIL_FUSION=1 — borders (zero padding of both
+    convolutions inside the tile), maps of 4, 6 and 10 tiles per side, batch > 1.  (The 16-bit eval bars against the oracle are test_bf16_* / test_config5_*; they run through this kernel too.)"""
+    from oracle import unet_oracle as O
+    O.set_seed(5)
+    ref = O.build_model().eval()
+    O.set_seed(5)
+    model = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev()).eval()
+    # non-trivial BatchNorm statistics (fresh running stats are 0 / 1: a weak test of the folded affines)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for (_, br), (_, bm) in zip(ref.named_buffers(), model.named_buffers()):
+            if br.dtype == torch.float32:
+                v = torch.rand(br.shape, generator=g) * 0.5 + (0.75 if br.min() >= 1.0 else -0.25)
+                br.copy_(v)
+                bm.copy_(v.to(bm.device))
+    model.mark_weights_dirty()
+    x, _ = O.synthetic_batch(n, s, seed=77)
+    xd = x.to(dev())
+
+    def run():
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+            return model(xd).float().clone()
+
+    monkeypatch.setenv("VK_NO_TAIL_FUSION", "1")
+    sep = run()
+    monkeypatch.delenv("VK_NO_TAIL_FUSION")
+    fused = run()
+    assert torch.equal(sep, fused), (sep - fused).abs().max().item()
+    assert torch.isfinite(fused).all() and fused.abs().max().item() > 0.1

@@ -121,6 +121,7 @@ SIGNATURES = {
     "vk_bn_bwd_apply_fused": (ci, [ci, sz, ci, vp, vp, ci, vp, vp, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
     "vk_upsample2x_bwd": (ci, [ci, ci, ci, ci, ci, vp, vp, ci, vp]),
     "vk_head_fwd": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp]),
+    "vk_dec4_tail_eval": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "vk_head_bwd": (ci, [ci, ci, ci, ci, P(vk_src), vp, vp, vp, vp, vp, vp, sz, vp]),
     "vk_bce_dice_loss": (ci, [sz, vp, vp, vp, vp, vp, cf, cf, cf, vp]),
     "vk_seg_metrics_workspace_bytes": (C.c_size_t, [ci]),

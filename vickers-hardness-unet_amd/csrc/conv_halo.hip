@@ -2120,12 +2120,11 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
     return u32x2_t{pk[0], pk[1]};
   };
   // byte offset of this lane's 4 channels (tile a) at output row y (pooled modes: the half-resolution pixel) in the output / in the
-  // bnr_z tensor, as a 32-bit buffer offset: lanes and rows that must not touch memory get an out-of-range offset, which a buffer load
-  // answers with zeros and a buffer store drops — no branches, no 64-bit address arithmetic per row (r03: the per-row `if (ok)`
-  // blocks with their own v_mad_u64 chains were a quarter of the instructions of the fused data-gradient row; K == 16 TC == ld here)
+  // bnr_z tensor, as a 32-bit offset: lanes and rows that must not touch memory get an out-of-range offset (top bit set), which a
+  // buffer load answers with zeros and the store skips — no 64-bit address arithmetic per row (r03: the per-row `if (ok)` blocks
+  // with their own v_mad_u64 chains were a quarter of the instructions of the fused data-gradient row; K == 16 TC == ld here)
   const int Ho = POOL ? Hh : p.H, Wo = POOL ? Wh : p.W;
   const uint32_t out_bytes = (uint32_t)((size_t)p.N * Ho * Wo * ld * 2);
-  const __amdgpu_buffer_rsrc_t rsy = make_rsrc(p.y0, out_bytes);
   const __amdgpu_buffer_rsrc_t rsbz = make_rsrc(BNR ? p.bnr_z : p.y0, out_bytes);
   const bool lane_stores = x_ok && (!POOL || (li & 1) == 0);
   const uint32_t lane_ob = lane_stores ? (uint32_t)(((n * Ho) * Wo + (POOL ? (xo >> 1) : xo)) * ld + kg * 4) * 2u : kOOB;
@@ -2160,7 +2159,12 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
         s2[a][e] += v * v;
       }
     }
-    __builtin_amdgcn_raw_buffer_store_b64(pk, rsy, boff, 0, 0);
+    // a plain (global) store under a lane predicate — NOT a buffer store: with MUBUF stores in the same vmcnt stream as the MUBUF row
+    // loads, the partial `s_waitcnt vmcnt(n)` waits the compiler places in front of the ring writes no longer guarantee that a row has
+    // arrived (r03: the no-statistics forward of the 32 -> 32 route consumed rows that were still in flight — wrong and different on
+    // every run, caught by the fused-vs-separate eval test; tests/diag/stream_determinism_diag.py reproduces it).  Loads through the
+    // descriptor are fine: loads return in order.
+    if ((int32_t)boff >= 0) *reinterpret_cast<u32x2_t*>((char*)p.y0 + boff) = pk;
   };
 
   // ---- the row pipeline.  Source row j lives in queue register set j & 3 until it is written to ring slot j & 3; the loop is
@@ -2270,6 +2274,207 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
         }
       }
   }
+}
+
+// ---- eval only (r03): decoder block 4 conv1 -> BN+ReLU -> conv2 -> BN+ReLU -> head in ONE kernel over an overlapping tile, 16-bit types.
+// In inference the BatchNorm affines are constants, so nothing forces the two 512^2 x 16 tensors between these three layers through
+// HBM (training cannot do this: the batch statistics need the whole tensor between the convolutions).  Per 16 x 16 logits tile:
+//   phase 0  the 12 x 12 SOURCE pixels (32 channels, half resolution) under the 22 x 22 upsampled window: BN+ReLU of the layer below,
+//            staged once as T (zeros outside the map);
+//   phase 1  conv1 on the 20 x 20 window: 25 groups of 16 linear pixels x 9 MFMAs (K = 32 = the 32 channels of one tap; the nearest-x2
+//            upsample is the index (p + d + 1) >> 1 into the source tile), rounded to T like the stored z1, BN1+ReLU as the consumer
+//            would apply it on load, zero outside the map (conv2's padding) -> LDS;
+//   phase 2  conv2 on the 18 x 18 window: 21 groups x 5 MFMAs (two taps of 16 channels per K = 32 step), rounded to T like the stored
+//            z2, BN2+ReLU in fp32 as the head applies it -> LDS (fp32);
+//   phase 3  the head's 144 FMAs per pixel from that tile (the code of k_head_fwd) -> logits.
+// Same operand order per accumulator as the kernels it replaces (conv3x3_stream_kernel, k_head_fwd): the same bits.  Redundant work:
+// (20/16)^2 on conv1, (18/16)^2 on conv2; HBM traffic per image 4.2 MB in + 1 MB out instead of 38.8 MB.
+struct TailCfg {
+  static constexpr int S_STRIDE = 96, A1_STRIDE = 48, A2_PS = 20;
+  static constexpr int S_BYTES = 144 * S_STRIDE;                    // 13,824
+  static constexpr int A1_BYTES = 400 * A1_STRIDE + 64;             // + a zero line (the non-existent tenth tap)
+  static constexpr int A2_BYTES = 324 * A2_PS * 4;
+  static constexpr int SMEM = S_BYTES + A1_BYTES + A2_BYTES;        // 59,008
+};
+
+struct TailParams {
+  const void* src;                 // [N][H/2][W/2][32] raw output of the layer below
+  const float* s0;                 // its BatchNorm affine (scale, shift), ReLU
+  const float* h0;
+  const void* w1;                  // conv1: halo pack, 16 rows x 32 channels
+  const float* s1;
+  const float* h1;
+  const void* w2;                  // conv2: plain [16][9][16]
+  const float* s2;
+  const float* h2;
+  const float* hw;                 // head [9][16] fp32
+  const float* hb;
+  float* logits;                   // [N][H][W]
+  int N, H, W;
+  uint32_t src_bytes;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void dec4_tail_eval_kernel(const TailParams p) {
+  using Cfg = TailCfg;
+  static_assert(sizeof(T) == 2, "16-bit element types");
+  constexpr int VE = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Sb = smem;
+  char* const A1 = smem + Cfg::S_BYTES;
+  float* const A2 = reinterpret_cast<float*>(smem + Cfg::S_BYTES + Cfg::A1_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
+  const int tiles_x = p.W >> 4, tiles_y = p.H >> 4;
+  int bt = blockIdx.x;
+  const int tx0 = bt % tiles_x;
+  bt /= tiles_x;
+  const int ty0 = bt % tiles_y;
+  const int n = bt / tiles_y;
+  const int y0 = ty0 * 16, x0 = tx0 * 16;
+  const int Hs = p.H >> 1, Ws = p.W >> 1;
+  const int sy0 = (y0 >> 1) - 2, sx0 = (x0 >> 1) - 2;
+  const __amdgpu_buffer_rsrc_t rss = make_rsrc(p.src, p.src_bytes);
+
+  // ---- weights as constant fragments (layouts of conv3x3_stream_kernel: halo pack for C = 32, plain [K][9][16] for C = 16)
+  u32x4_t wf1[9], wf2[5];
+#pragma unroll
+  for (int st = 0; st < 9; ++st) {
+    const int pos = kg ^ (((li >> 2) & 1) << 1);
+    wf1[st] = *reinterpret_cast<const u32x4_t*>((const char*)p.w1 + ((st * 16 + li) * 4 + pos) * 16);
+  }
+#pragma unroll
+  for (int st = 0; st < 5; ++st) {
+    const int tap = 2 * st + (kg >> 1);
+    wf2[st] = u32x4_t{0, 0, 0, 0};
+    if (tap < 9) wf2[st] = *reinterpret_cast<const u32x4_t*>((const char*)p.w2 + ((li * 9 + tap) * 16 + (kg & 1) * VE) * 2);
+  }
+  float sc1[8], sh1[8], sc2[4], sh2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sc1[e] = p.s1[kg * 4 + e]; sh1[e] = p.h1[kg * 4 + e];
+    sc1[4 + e] = 0.f; sh1[4 + e] = 0.f;
+    sc2[e] = p.s2[kg * 4 + e]; sh2[e] = p.h2[kg * 4 + e];
+  }
+  if (tid < 4) *reinterpret_cast<u32x4_t*>(A1 + 400 * Cfg::A1_STRIDE + tid * 16) = u32x4_t{0, 0, 0, 0};
+
+  // ---- phase 0: source tile, 144 pixels x 4 pieces
+  {
+    float sc0[VE], sh0[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { sc0[j] = p.s0[(tid & 3) * VE + j]; sh0[j] = p.h0[(tid & 3) * VE + j]; }
+    u32x4_t r[3];
+    bool ok[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int v = tid + 256 * q;
+      const int px = v >> 2;
+      const int sy = sy0 + px / 12, sx = sx0 + px % 12;
+      ok[q] = v < 576 && (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;
+      r[q] = buf_load16(rss, ok[q] ? (uint32_t)((((n * Hs + sy) * Ws + sx) * 32 + (v & 3) * VE) * 2) : kOOB);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int v = tid + 256 * q;
+      if (v >= 576) continue;
+      u32x4_t x = AffineRelu<T>::run(r[q], sc0, sh0, true);
+      if (!ok[q]) x = u32x4_t{0, 0, 0, 0};
+      *reinterpret_cast<u32x4_t*>(Sb + (v >> 2) * Cfg::S_STRIDE + (v & 3) * 16) = x;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1: conv1 on the 20 x 20 window (origin (y0 - 2, x0 - 2)); group = 16 consecutive linear pixels
+  for (int g = wave; g < 25; g += 4) {
+    const int pl = g * 16 + li;
+    const int py = pl / 20, px = pl - py * 20;
+    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 9; ++st) {
+      const int r = st / 3, sxx = st - r * 3;
+      const int srow = (py + r + 1) >> 1, scol = (px + sxx + 1) >> 1;      // nearest-x2: window pixel + tap -> source tile pixel
+      const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(Sb + (srow * 12 + scol) * Cfg::S_STRIDE + kg * 16);
+      acc = Mma<T>::run(wf1[st], xf, acc);
+    }
+    float f[8] = {acc[0], acc[1], acc[2], acc[3], 0.f, 0.f, 0.f, 0.f};
+    const u32x4_t z1 = Vec16<T>::pack(f);                                   // the value conv1 would have stored
+    u32x4_t a1 = AffineRelu<T>::run(z1, sc1, sh1, true);                    // ... and conv2 would have staged
+    const int Y = y0 - 2 + py, X = x0 - 2 + px;
+    if ((unsigned)Y >= (unsigned)p.H || (unsigned)X >= (unsigned)p.W) a1 = u32x4_t{0, 0, 0, 0};      // conv2's zero padding
+    *reinterpret_cast<u32x2_t*>(A1 + pl * Cfg::A1_STRIDE + kg * 8) = u32x2_t{a1[0], a1[1]};
+  }
+  __syncthreads();
+
+  // ---- phase 2: conv2 on the 18 x 18 window (origin (y0 - 1, x0 - 1)), two taps per K = 32 step
+  for (int g = wave; g < 21; g += 4) {
+    const int ql = g * 16 + li;
+    const bool live = ql < 324;
+    const int q = live ? ql : 0;
+    const int qy = q / 18, qx = q - qy * 18;
+    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const int tap = 2 * st + (kg >> 1);
+      const int r = tap / 3, sxx = tap - r * 3;
+      const int addr = tap < 9 ? ((qy + r) * 20 + qx + sxx) * Cfg::A1_STRIDE + (kg & 1) * 16 : 400 * Cfg::A1_STRIDE;
+      const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(A1 + addr);
+      acc = Mma<T>::run(wf2[st], xf, acc);
+    }
+    float f[8] = {acc[0], acc[1], acc[2], acc[3], 0.f, 0.f, 0.f, 0.f};
+    const u32x4_t z2 = Vec16<T>::pack(f);                                   // the value conv2 would have stored
+    Vec16<T>::unpack(z2, f);
+    const int Y = y0 - 1 + qy, X = x0 - 1 + qx;
+    const bool inside = (unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W;
+    f32x4_t a2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a2[e] = inside ? fmaxf(fmaf(f[e], sc2[e], sh2[e]), 0.f) : 0.f;      // as k_head_fwd stages it (fp32)
+    if (live) *reinterpret_cast<f32x4_t*>(A2 + q * Cfg::A2_PS + kg * 4) = a2;
+  }
+  __syncthreads();
+
+  // ---- phase 3: the head (k_head_fwd's arithmetic, same order)
+  {
+    const int ty = tid >> 4, tx = tid & 15;
+    typedef float f32x2_t_ __attribute__((ext_vector_type(2)));
+    f32x2_t_ acc_a = f32x2_t_{p.hb[0], 0.f}, acc_b = f32x2_t_{0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        const float* a = A2 + ((ty + r) * 18 + tx + s_) * Cfg::A2_PS;
+        const float* wt = p.hw + (r * 3 + s_) * 16;
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {
+          const f32x4_t av = *reinterpret_cast<const f32x4_t*>(a + j);
+          acc_a = __builtin_elementwise_fma(f32x2_t_{av[0], av[1]}, f32x2_t_{wt[j], wt[j + 1]}, acc_a);
+          acc_b = __builtin_elementwise_fma(f32x2_t_{av[2], av[3]}, f32x2_t_{wt[j + 2], wt[j + 3]}, acc_b);
+        }
+      }
+    p.logits[((size_t)n * p.H + y0 + ty) * p.W + x0 + tx] = (acc_a[0] + acc_a[1]) + (acc_b[0] + acc_b[1]);
+  }
+}
+
+int dec4_tail_eval_impl(vk_dtype dt, int N, int H, int W, const vk_src* src, const void* w1_pack, const float* scale1, const float* shift1,
+                        const void* w2_plain, const float* scale2, const float* shift2, const float* head_w, const float* head_b, float* logits,
+                        hipStream_t st) {
+  VK_CHECK_ARG(dt != VK_F32, "vk_dec4_tail_eval: 16-bit element types only");
+  VK_CHECK_ARG(src && src->ptr && src->C == 32 && src->up == 1 && src->scale && src->shift && src->relu, "vk_dec4_tail_eval: source must be 32 channels, upsampled, with its BN+ReLU");
+  VK_CHECK_ARG(w1_pack && scale1 && shift1 && w2_plain && scale2 && shift2 && head_w && head_b && logits, "vk_dec4_tail_eval: null argument");
+  VK_CHECK_ARG(N > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, "vk_dec4_tail_eval: %d x %d is not a multiple of 16", H, W);
+  VK_CHECK_ARG((size_t)N * (H / 2) * (W / 2) * 32 * 2 < (1ull << 31), "vk_dec4_tail_eval: source of 2 GiB or more");
+  TailParams p;
+  p.src = src->ptr; p.s0 = src->scale; p.h0 = src->shift;
+  p.w1 = w1_pack; p.s1 = scale1; p.h1 = shift1;
+  p.w2 = w2_plain; p.s2 = scale2; p.h2 = shift2;
+  p.hw = head_w; p.hb = head_b; p.logits = logits;
+  p.N = N; p.H = H; p.W = W;
+  p.src_bytes = (uint32_t)((size_t)N * (H / 2) * (W / 2) * 32 * 2);
+  const unsigned nb = (unsigned)((size_t)N * (H / 16) * (W / 16));
+  const double px = (double)N * H * W;
+  vkh::ProfScope ps("dec4_tail_eval_16b", st, 2.0 * px * (9.0 * 32 * 16 + 9.0 * 16 * 16 + 144.0), px * (32.0 * 2 / 4 + 4.0));
+  if (dt == VK_BF16) hipLaunchKernelGGL(dec4_tail_eval_kernel<bf16_t>, dim3(nb), dim3(256), TailCfg::SMEM, st, p);
+  else hipLaunchKernelGGL(dec4_tail_eval_kernel<f16_t>, dim3(nb), dim3(256), TailCfg::SMEM, st, p);
+  VK_CHECK_HIP(hipGetLastError());
+  return VK_OK;
 }
 
 // ---- weight repack into the halo layout.  src: [rows][9][red] of T (rows = output channels of the GEMM: K for forward
@@ -2725,3 +2930,11 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, 
 }
 
 }  // namespace vk
+
+extern "C" int vk_dec4_tail_eval(vk_dtype dtype, int N, int H, int W, const vk_src* src, const void* w1_pack, const float* scale1,
+                                 const float* shift1, const void* w2_plain, const float* scale2, const float* shift2, const float* head_w9x16,
+                                 const float* head_bias, float* logits, void* stream) {
+  return vk::dec4_tail_eval_impl(dtype, N, H, W, src, w1_pack, scale1, shift1, w2_plain, scale2, shift2, head_w9x16, head_bias, logits,
+                                 (hipStream_t)stream);
+}
+

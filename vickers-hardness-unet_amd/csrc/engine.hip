@@ -1009,6 +1009,16 @@ extern "C" int vk_unet_forward(vk_unet* h, const float* x, float* logits, int tr
     DecL& d = h->decs[i];
     ConvL& c1 = h->convs[d.conv1];
     ConvL& c2 = h->convs[d.conv2];
+    // inference, 16-bit: the last block and the head as ONE kernel over an overlapping tile (vk_dec4_tail_eval): the folded BatchNorm
+    // affines are constants, nothing forces the two 512^2 x 16 tensors through HBM.  VK_NO_TAIL_FUSION=1: the three separate launches
+    if (!training && i + 1 == h->decs.size() && dt != VK_F32 && !d.Cskip && d.Cup == 32 && c1.K == 16 && c2.K == 16 && c1.halo_fwd &&
+        !c2.halo_fwd && S % 16 == 0 && !getenv("VK_NO_TAIL_FUSION")) {
+      const vk_src s0 = to_src(xd, 1);
+      const BnL& b1 = h->bns[c1.bn];
+      const BnL& b2 = h->bns[c2.bn];
+      return vk_dec4_tail_eval(dt, N, S, S, &s0, fwd_weights(h, c1), b1.scale, b1.shift, fwd_weights(h, c2), b2.scale, b2.shift,
+                               h->params + h->head_w_off, h->params + h->head_b_off, logits, st);
+    }
     RET_IF(run_conv(h, c1, to_src(xd, 1), d.Cskip ? to_src(skips[i]) : null_src(), training, st));
     RET_IF(run_conv(h, c2, to_src(bn_act(h, c1)), null_src(), training, st));
     xd = bn_act(h, c2);
