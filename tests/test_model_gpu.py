@@ -600,6 +600,7 @@ def test_eval_decoder_tail_fusion_matches_separate_launches(monkeypatch, dtype, 
     monkeypatch.setenv("VK_NO_TAIL_FUSION", "1")
     sep = run()
     monkeypatch.delenv("VK_NO_TAIL_FUSION")
+    monkeypatch.setenv("VK_TAIL_FUSION", "1")          # also for plans the engine would not fuse by itself (it fuses small ones only)
     fused = run()
     assert torch.equal(sep, fused), (sep - fused).abs().max().item()
     assert torch.isfinite(fused).all() and fused.abs().max().item() > 0.1

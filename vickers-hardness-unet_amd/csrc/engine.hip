@@ -1009,10 +1009,14 @@ extern "C" int vk_unet_forward(vk_unet* h, const float* x, float* logits, int tr
     DecL& d = h->decs[i];
     ConvL& c1 = h->convs[d.conv1];
     ConvL& c2 = h->convs[d.conv2];
-    // inference, 16-bit: the last block and the head as ONE kernel over an overlapping tile (vk_dec4_tail_eval): the folded BatchNorm
-    // affines are constants, nothing forces the two 512^2 x 16 tensors through HBM.  VK_NO_TAIL_FUSION=1: the three separate launches
+    // inference, 16-bit, SMALL plans (single-image inference: launch-bound): the last block and the head as ONE kernel over an
+    // overlapping tile (vk_dec4_tail_eval; the folded BatchNorm affines are constants, nothing forces the two 512^2 x 16 tensors through
+    // HBM).  Measured (profiles/r03/eval_tail_fusion.log): batch 1 0.691 -> 0.671 ms, but batch 16 1.690 -> 1.734 ms — the fused
+    // tile's redundant halo work and three barriers cost more than the 33 MB per image they save against the streaming kernels — so
+    // large plans keep the three launches.  VK_NO_TAIL_FUSION=1 / VK_TAIL_FUSION=1: never / always
+    const bool small_plan = (size_t)N * S * S <= 4u * 512 * 512;
     if (!training && i + 1 == h->decs.size() && dt != VK_F32 && !d.Cskip && d.Cup == 32 && c1.K == 16 && c2.K == 16 && c1.halo_fwd &&
-        !c2.halo_fwd && S % 16 == 0 && !getenv("VK_NO_TAIL_FUSION")) {
+        !c2.halo_fwd && S % 16 == 0 && !getenv("VK_NO_TAIL_FUSION") && (small_plan || getenv("VK_TAIL_FUSION"))) {
       const vk_src s0 = to_src(xd, 1);
       const BnL& b1 = h->bns[c1.bn];
       const BnL& b2 = h->bns[c2.bn];
