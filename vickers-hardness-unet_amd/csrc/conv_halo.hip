@@ -2159,9 +2159,9 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
         s2[a][e] += v * v;
       }
     }
-    // a plain (global) store under a lane predicate — NOT a buffer store: with MUBUF stores in the same vmcnt stream as the MUBUF row
-    // loads, the partial `s_waitcnt vmcnt(n)` waits the compiler places in front of the ring writes no longer guarantee that a row has
-    // arrived (r03: the no-statistics forward of the 32 -> 32 route consumed rows that were still in flight — wrong and different on
+    // a plain (global) store under a lane predicate — NOT a buffer store: with `raw_buffer_store` in the same kernel as the MUBUF row
+    // loads, the partial `s_waitcnt vmcnt(n)` waits the compiler places in front of the ring writes no longer covered the loads (stores
+    // retiring out of order with the loads, or not counted by the compiler: not resolved) (r03: the no-statistics forward of the 32 -> 32 route consumed rows that were still in flight — wrong and different on
     // every run, caught by the fused-vs-separate eval test; tests/diag/stream_determinism_diag.py reproduces it).  Loads through the
     // descriptor are fine: loads return in order.
     if ((int32_t)boff >= 0) *reinterpret_cast<u32x2_t*>((char*)p.y0 + boff) = pk;
