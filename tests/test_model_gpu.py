@@ -604,3 +604,62 @@ def test_eval_decoder_tail_fusion_matches_separate_launches(monkeypatch, dtype, 
     fused = run()
     assert torch.equal(sep, fused), (sep - fused).abs().max().item()
     assert torch.isfinite(fused).all() and fused.abs().max().item() > 0.1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("n,s", [(2, 64), (1, 160)])
+def test_eval_16bit_kernel_paths_agree_and_repeat(monkeypatch, dtype, n, s):
+    """16-bit inference through three independent kernel families — the default (tile + streaming kernels, fused tail), the tile kernels
+    alone (VK_NO_STREAM + VK_NO_TAIL_FUSION) and the tap-by-tap kernels (VK_NO_HALO) — must give the same logits up to 16-bit rounding,
+    and the default path the SAME BITS on every run.  (r03: an epilogue variant of the streaming kernel gave wrong, run-to-run different
+    values in exactly this launch class — inference passes no statistics pointer — while every per-kernel test, all of which passed
+    one, stayed green.)"""
+    from oracle import unet_oracle as O
+    O.set_seed(11)
+    model = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev()).eval()
+    x, _ = O.synthetic_batch(n, s, seed=91)
+    xd = x.to(dev())
+
+    def run(**env):
+        for k in ("VK_NO_STREAM", "VK_NO_TAIL_FUSION", "VK_NO_HALO"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+            return model(xd).float().clone()
+
+    base = run()
+    for _ in range(3):
+        assert torch.equal(run(), base)
+    tile = run(VK_NO_STREAM="1", VK_NO_TAIL_FUSION="1")
+    tap = run(VK_NO_HALO="1", VK_NO_TAIL_FUSION="1")
+    bar = (2e-2 if dtype == torch.bfloat16 else 3e-3) * (1.0 + base.abs().max().item())
+    assert (tile - base).abs().max().item() <= bar
+    assert (tap - base).abs().max().item() <= bar
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+def test_training_steps_are_bit_reproducible(dtype):
+    """Two replicas built from the same seed, fed the same batches, stepped three times (fused loss + backward, AdamW): every parameter
+    and BatchNorm buffer must end with the SAME BITS.  Nothing on the training path may depend on timing: weight gradients are summed
+    from slabs / partial tiles in a fixed order, the BatchNorm sums are fp64 atomics of fp32 partials (exact at these sizes), no kernel
+    reads memory it has not waited for.  128 x 128 so that every kernel family of the real step (tile, streaming, batched weight
+    gradients with several segments per workgroup, fused head backward) takes part."""
+    from oracle import unet_oracle as O
+    finals = []
+    for rep in range(2):
+        O.set_seed(21)
+        m = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev()).train()
+        opt = vk.adamw_for(m, lr=1e-3, weight_decay=1e-4)
+        for step in range(3):
+            x, y = O.synthetic_batch(4, 128, seed=300 + step)
+            opt.zero_grad(set_to_none=True)
+            out = m.loss_and_backward(x.to(dev()), y.to(dev()), dtype=dtype)
+            opt.step()
+        torch.cuda.synchronize()
+        state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        finals.append((state, out.clone()))
+    (a, la), (b, lb) = finals
+    assert torch.equal(la, lb)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
