@@ -57,11 +57,16 @@ def main():
     ap.add_argument("--api-steps", type=int, default=10, help="timed steps of the drop-in API path (0 = skip)")
     args = ap.parse_args()
 
+    # --gpus N without a launcher: start the N ranks ourselves (a child process, never an exec: nothing has touched the GPU yet, and
+    # the child's ranks initialise it themselves), relay their output and exit with the launcher's code
+    action, info = launch_plan(args.gpus, os.environ)
+    if action == "spawn":
+        raise SystemExit(self_launch(info, sys.argv[1:]))
+    if action == "error":
+        raise SystemExit(info)
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = info
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     # rehearsal of the multi-rank control flow on a ONE-GPU box: VK_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
@@ -210,6 +215,26 @@ def main():
     if rank == 0:
         L.vk_prof_enable(0)
         table = vk._lib.prof_collect()
+    # ---- overlap budget of the data-parallel policies: the backward issued in the "deferred" grouping — stages 0-8 as one call (one
+    # weight-gradient batch), stage 9 (layer 1 + stem) as the second — with a HIP event pair around each call.  The collective that
+    # carries 99 % of the gradient bytes is issued between the two, so the second duration is the window it can hide under.
+    if args.mode == "train":
+        if red is not None:
+            groups_ms = model.group_times_ms()         # the profile steps above ran with red.timing: the policy's own grouping
+        else:
+            model._time_groups = [(0, 9), (9, 10)]
+            for _ in range(max(1, args.prof_steps)):
+                step()
+            torch.cuda.synchronize()
+            groups_ms = model.group_times_ms()
+            model._time_groups = None
+        budget = {f"stages_{a}_{b - 1}_ms" if b - a > 1 else f"stage_{a}_ms": round(sum(v) / len(v), 3) for (a, b), v in sorted(groups_ms.items())}
+        if dp_info is None:
+            dp_info = {"policy": "deferred (grouping only: single rank, no collective)"}
+        dp_info["backward_group_ms"] = budget
+        dp_info["overlap_window_note"] = ("HIP events around each vk_unet_backward call of the policy's grouping; under 'deferred' the one large "
+                                          "all-reduce (buckets 0-8, ~97 MB fp32) is issued after stages 0-8 and can only hide under stage 9")
+    if rank == 0:
         _log("event profile collected")
         if table:
             # group like rocprofv3 does (by kernel symbol): forward and data-gradient launches of one kernel share a family
@@ -357,14 +382,16 @@ def main():
 
     if rank == 0:
         ips = world * N * args.steps / dt
+        ci = baseline_config_index(args.mode, S, args.dtype, N, world)
+        cfg_label = f"BASELINE.json configs[{ci}]" if ci is not None else "not a BASELINE.json config"
         rec = {
             "metric": ("512x512 images/sec (train fwd+bwd)" if args.mode == "train" else "512x512 images/sec (eval fwd)")
             if S == 512 else f"{S}x{S} images/sec ({args.mode})",
             "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"unet_r34_{S} {args.dtype} {'train fwd+loss+bwd+AdamW' if args.mode == 'train' else 'eval forward'}, "
-                                   f"bs={N}/GPU, BCE+Dice, synthetic {S}x{S} (BASELINE.json configs[{2 if args.mode == 'train' else 1}])",
+            "config": {"workload": f"unet_r34_{S} {args.dtype} {'train fwd+loss+bwd+AdamW, BCE+Dice' if args.mode == 'train' else 'eval forward'}, "
+                                   f"bs={N}/GPU, synthetic {S}x{S} ({cfg_label})",
                        "global_batch": world * N, "image_size": S,
                        "parallelism": (f"dp{world} (RCCL all-reduce of fp32 gradients over 10 backward-ordered buckets, issue policy "
                                        f"{getattr(getattr(model, '_reducer', None), 'policy', '?')}: see parallel.py)") if world > 1 else "single GPU"},
@@ -377,6 +404,49 @@ def main():
         print(json.dumps(rec), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
+
+
+def launch_plan(gpus: int, env) -> tuple:
+    """What `bench.py --gpus N` has to do in this environment: ("run", world) — this process is a rank (or the single process) and the
+    world size agrees with --gpus; ("spawn", N) — no launcher around us and N > 1: start N ranks; ("error", message) — the launcher's
+    WORLD_SIZE contradicts --gpus (a line with the wrong n_gpus must never be printed)."""
+    if gpus < 1:
+        return "error", f"--gpus {gpus}: need at least one GPU"
+    ws = env.get("WORLD_SIZE")
+    if ws is None:
+        return ("run", 1) if gpus == 1 else ("spawn", gpus)
+    world = int(ws)
+    if world != gpus:
+        return "error", f"--gpus {gpus} but WORLD_SIZE={world}: refusing to print a line with the wrong n_gpus"
+    return "run", world
+
+
+def self_launch(n: int, argv) -> int:
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port P bench.py <argv>` as a
+    child process (the form the driver itself uses for N > 1); its stdout / stderr are inherited, its exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    _log(f"--gpus {n} without a launcher: starting {' '.join(cmd[1:8])} ...")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def baseline_config_index(mode: str, size: int, dtype: str, batch: int, world: int):
+    """Which BASELINE.json configs[] entry a run is (None: not one of them)."""
+    if mode == "infer" and size == 512 and dtype == "fp32" and batch == 16 and world == 1:
+        return 1
+    if mode == "train" and size == 512 and dtype == "bf16" and batch == 32:
+        return 2 if world == 1 else 3
+    if mode == "train" and size == 1024 and dtype == "fp16" and batch == 8:
+        return 4
+    return None
 
 
 def kernel_source_hash() -> str:

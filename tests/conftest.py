@@ -25,3 +25,13 @@ def vk():
 def oracle():
     from oracle import unet_oracle
     return unet_oracle
+
+
+def golden_loops_batches():
+    """The seeded (x, y, names) loaders of tests/golden/loops_ref.json (defined once, next to the script that ran the reference's
+    own loops over them; importing that script reads nothing from /root/reference)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vk_make_golden", GOLDEN / "make_golden.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.loops_batches()

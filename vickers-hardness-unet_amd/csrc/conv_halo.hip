@@ -1966,6 +1966,9 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const HaloParams p) {
 // C = 32 the tile kernels add (filter column, filter row) instead: results differ in fp32 rounding order (a last-bit flip of the
 // stored value on < 5 % of the elements, tests/test_ops_gpu.py::test_stream_conv_kernels_match_tile_kernels).  Statistics are over the
 // stored (rounded) values, pooling adds the four rounded values in the tile kernels' order.
+#ifndef VK_STREAM_DIAG
+#define VK_STREAM_DIAG 0      // diagnostic builds only (tests/diag/stream_race_diag.py)
+#endif
 template <typename T, int CIN, bool UP>
 struct StreamCfg {
   static constexpr int NSTEP = CIN == 16 ? 5 : 9;
@@ -2070,6 +2073,9 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
   auto write_row = [&](int j, const u32x4_t (&r)[NLD]) {
     const bool rok = (unsigned)j < (unsigned)Hs;
     char* const slot = ring + (j & 3) * ROWB;
+#if (VK_STREAM_DIAG & 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
     for (int q = 0; q < NLD; ++q) {
       if (st_off[q] < 0) continue;
@@ -2080,6 +2086,9 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
       }
       *reinterpret_cast<u32x4_t*>(slot + st_off[q]) = v;
     }
+#if (VK_STREAM_DIAG & 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
   };
 
   // ---- fragment-read geometry: step -> (filter row r, column s); C = 16: per lane (two taps per step), C = 32: per step
@@ -2126,6 +2135,9 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
   const int Ho = POOL ? Hh : p.H, Wo = POOL ? Wh : p.W;
   const uint32_t out_bytes = (uint32_t)((size_t)p.N * Ho * Wo * ld * 2);
   const __amdgpu_buffer_rsrc_t rsbz = make_rsrc(BNR ? p.bnr_z : p.y0, out_bytes);
+#ifdef VK_STREAM_BUFSTORE
+  const __amdgpu_buffer_rsrc_t rsy = make_rsrc(p.y0, out_bytes);
+#endif
   const bool lane_stores = x_ok && (!POOL || (li & 1) == 0);
   const uint32_t lane_ob = lane_stores ? (uint32_t)(((n * Ho) * Wo + (POOL ? (xo >> 1) : xo)) * ld + kg * 4) * 2u : kOOB;
   const uint32_t row_ob = (uint32_t)(Wo * ld * 2);
@@ -2159,12 +2171,21 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
         s2[a][e] += v * v;
       }
     }
-    // a plain (global) store under a lane predicate — NOT a buffer store: with `raw_buffer_store` in the same kernel as the MUBUF row
-    // loads, the partial `s_waitcnt vmcnt(n)` waits the compiler places in front of the ring writes no longer covered the loads (stores
-    // retiring out of order with the loads, or not counted by the compiler: not resolved) (r03: the no-statistics forward of the 32 -> 32 route consumed rows that were still in flight — wrong and different on
-    // every run, caught by the fused-vs-separate eval test; tests/diag/stream_determinism_diag.py reproduces it).  Loads through the
-    // descriptor are fine: loads return in order.
+    // a plain (global) store under a lane predicate.  (r03 blamed MUBUF stores for the wrong 16-bit inference of 04e3d09..75808a4;
+    // r04 found the cause elsewhere — an MFMA-result read 2 wait states behind its MFMA across a branch, see the sched_barrier in
+    // row() — and tests/diag/vmcnt_order_probe.hip shows stores never leave the vmcnt queue ahead of older loads on this chip:
+    // 0 of 2.1 M wave-probes.  VK_STREAM_BUFSTORE rebuilds the MUBUF form for tests/diag/stream_race_diag.py.)
+#ifdef VK_STREAM_BUFSTORE      // diagnostic build only (r03 bug reconstruction, tests/diag/README.md): the MUBUF store form
+#if (VK_STREAM_DIAG & 8)
+    if ((int32_t)boff >= 0)
+#endif
+    __builtin_amdgcn_raw_buffer_store_b64(pk, rsy, boff, 0, 0);
+#if (VK_STREAM_DIAG & 4)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#else
     if ((int32_t)boff >= 0) *reinterpret_cast<u32x2_t*>((char*)p.y0 + boff) = pk;
+#endif
   };
 
   // ---- the row pipeline.  Source row j lives in queue register set j & 3 until it is written to ring slot j & 3; the loop is
@@ -2218,6 +2239,16 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
 #pragma unroll
       for (int a = 0; a < TC; ++a) acc[a] = Mma<T>::run(wf[st][a], xf, acc[a]);
     }
+    // Every MFMA of the row stays in front of every accumulator read of its epilogue.  r03's wrong 16-bit inference (root cause found in
+    // r04): with MUBUF stores in the epilogue hipcc sank the row's LAST MFMA (tile 1) below tile 0's accumulator
+    // reads, directly in front of the wave-uniform `want_sums` branch, and the block at the branch target opens with the
+    // v_accvgpr_read of that MFMA's result — 2 wait states behind it on the taken edge (no statistics pointer) instead of the 8 the
+    // hazard recogniser pads everywhere else: element 3 of every lane's channel group came out stale in every fourth output row.
+    // With the barrier the last MFMA is followed by straight-line code (padded correctly); tools/mfma_hazard_audit.py checks the
+    // shipped binary for this pattern along every control-flow path (tests/test_host_cpu.py).
+#if !(VK_STREAM_DIAG & 16)      // 16: the r03 code without the barrier (diagnostic builds only)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const bool y_ok = y < p.H;
 #pragma unroll
     for (int a = 0; a < TC; ++a) {

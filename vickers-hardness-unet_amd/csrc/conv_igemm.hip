@@ -520,9 +520,8 @@ static bool is_c16(const vk_conv_desc* d) {
   return d->dtype != VK_F32 && d->src0.C == 16 && !d->src1.ptr && !d->src0.up;
 }
 
-static bool halo_enabled() {
-  static const bool on = getenv("VK_NO_HALO") == nullptr;
-  return on;
+static bool halo_enabled() {       // read per call (diagnostic switch): a plan bound under VK_NO_HALO holds no halo packs
+  return getenv("VK_NO_HALO") == nullptr;
 }
 
 int conv_fwd_impl(const vk_conv_desc* d, const void* w, int packed, void* y, void* y1, int split_k1, int accumulate,

@@ -142,6 +142,9 @@ __global__ __launch_bounds__(256) void k_mfma_rate(int iters, float* sink) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
   }
+  // the MFMAs above are inline assembly: hipcc pads no hazard for them, and the first read of acc[7] below sits 1 wait state behind
+  // its MFMA on the loop-exit edge (tools/mfma_hazard_audit.py, r04) — 8 states are required before a VALU read of a 16x16x32 result
+  asm volatile("s_nop 7\n\ts_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
   float t = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];

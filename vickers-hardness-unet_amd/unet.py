@@ -143,6 +143,8 @@ class Unet(nn.Module):
         self._plans: Dict[tuple, _Plan] = {}
         self._dirty = 0
         self._reducer = None
+        self._time_groups = None
+        self._group_events = []
         self._anchor = torch.zeros((), requires_grad=True)
         self._build_tree()
         self._rebuild_views()
@@ -336,18 +338,34 @@ class Unet(nn.Module):
             check(L.vk_unet_set_side_stream(plan.h, 0), "vk_unet_set_side_stream")    # see include/vk_unet.h
             plan._side_off = True
         capped = False
-        if red is None and not os.environ.get("VK_BACKWARD_PER_STAGE"):
+        # bench.py's overlap budget: `_time_groups` = [begin, end) stage ranges to run as separate calls with a HIP event pair around
+        # each (the grouping of the "deferred" policy is [(0, 9), (9, 10)]); durations are read with group_times_ms()
+        tg = getattr(self, "_time_groups", None)
+        if red is None and tg is None and not os.environ.get("VK_BACKWARD_PER_STAGE"):
             # nobody needs a stage's gradients before the end: one call, so that the weight gradients of ALL stages run as one batch
             check(L.vk_unet_backward(plan.h, _lib.ptr(dlogits), 0, plan.nbuckets, st), "vk_unet_backward")
             return
-        groups = red.stage_groups(plan.nbuckets) if hasattr(red, "stage_groups") and not os.environ.get("VK_BACKWARD_PER_STAGE") \
-            else [(s, s + 1) for s in range(plan.nbuckets)]
+        if os.environ.get("VK_BACKWARD_PER_STAGE"):
+            groups = [(s, s + 1) for s in range(plan.nbuckets)]
+        elif red is not None and hasattr(red, "stage_groups"):
+            groups = red.stage_groups(plan.nbuckets)
+        elif tg is not None:
+            groups = [tuple(g) for g in tg]
+        else:
+            groups = [(s, s + 1) for s in range(plan.nbuckets)]
+        timed = tg is not None or (red is not None and getattr(red, "timing", False))
         try:
             for s0, s1 in groups:
-                if red is not None and red.reserved_cus > 0 and red.in_flight and not capped:
+                if red is not None and getattr(red, "reserved_cus", 0) > 0 and getattr(red, "in_flight", False) and not capped:
                     L.vk_set_reserved_cus(red.reserved_cus)      # collectives share the chip from here on: see parallel.py
                     capped = True
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 check(L.vk_unet_backward(plan.h, _lib.ptr(dlogits), s0, s1, st), "vk_unet_backward")
+                if timed:
+                    e1.record()
+                    self._group_events.append((s0, s1, e0, e1))
                 if red is not None:
                     for s in range(s0, s1):
                         red.bucket_ready(s, plan.buckets[s])
@@ -356,6 +374,15 @@ class Unet(nn.Module):
                 L.vk_set_reserved_cus(0)
         if red is not None:
             red.finish()
+
+    def group_times_ms(self):
+        """Durations of the timed backward groups since the last call: {(begin, end): [ms per step, ...]} (synchronises)."""
+        out = {}
+        for s0, s1, e0, e1 in self._group_events:
+            e1.synchronize()
+            out.setdefault((s0, s1), []).append(e0.elapsed_time(e1))
+        self._group_events.clear()
+        return out
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_input(x)
