@@ -179,7 +179,9 @@ int vk_conv_wgrad(const vk_conv_desc* d, const void* dz, float* dw, void* worksp
  * The (layer, output tile, 128-pixel tile) units of all layers are cut into `workgroups` equal ranges (0: one per usable CU); ranges
  * that cross an output tile leave partial tiles in `workspace`, which a second kernel adds in range order: same bits on every run.
  * At most 40 layers.  Replaces the per-layer launches of a backward stage (the reference: autograd's per-layer convolution-backward-weight calls behind
- * train.py:443 / :448).  `tables`: device scratch of VK_WGRAD_BATCH_TABLE_BYTES, filled (synchronously) by the call; dw[l] += result. */
+ * train.py:443 / :448).  `tables`: device scratch of VK_WGRAD_BATCH_TABLE_BYTES, filled (synchronously) by the call; dw[l] += result.
+ * The call waits for `stream` (hipStreamSynchronize) before it refills `tables`, so the same tables / workspace may be passed to
+ * consecutive calls; buffers shared with work on OTHER streams are the caller's to order. */
 #define VK_WGRAD_BATCH_TABLE_BYTES (128u << 10)
 int vk_conv_wgrad_batch_supports(const vk_conv_desc* d);
 int vk_conv_wgrad_batch(const vk_conv_desc* descs, const void* const* dz, float* const* dw, int n, int workgroups, void* tables,

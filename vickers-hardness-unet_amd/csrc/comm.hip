@@ -33,6 +33,7 @@ struct Rccl {
   fn_broadcast broadcast = nullptr;
   fn_errstr errstr = nullptr;
   bool ok = false;
+  char why[256] = {0};            // why the library is unusable (captured once, inside call_once)
 };
 
 Rccl& rccl() {
@@ -43,6 +44,7 @@ Rccl& rccl() {
     for (const char* n : names) {
       r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
       if (r.so) break;
+      if (const char* e = dlerror()) snprintf(r.why, sizeof(r.why), "%s", e);      // dlerror() clears itself: keep the text of the last attempt
     }
     if (!r.so) return;
     r.get_id = (fn_get_id)dlsym(r.so, "ncclGetUniqueId");
@@ -52,13 +54,14 @@ Rccl& rccl() {
     r.broadcast = (fn_broadcast)dlsym(r.so, "ncclBroadcast");
     r.errstr = (fn_errstr)dlsym(r.so, "ncclGetErrorString");
     r.ok = r.get_id && r.init_rank && r.destroy && r.allreduce && r.broadcast;
+    if (!r.ok) snprintf(r.why, sizeof(r.why), "a required ncclXxx symbol is missing");
   });
   return r;
 }
 
 int need_rccl(const char* who) {
   if (rccl().ok) return VK_OK;
-  vkh::set_error("%s: librccl.so could not be opened (%s)", who, dlerror() ? dlerror() : "symbols missing");
+  vkh::set_error("%s: librccl.so is not usable (%s)", who, rccl().why[0] ? rccl().why : "unknown reason");
   return VK_ERR_STATE;
 }
 
@@ -109,12 +112,14 @@ extern "C" int vk_comm_world(const vk_comm* c) { return c ? c->world : 0; }
 
 extern "C" int vk_allreduce_bucket(vk_comm* c, float* grads, size_t count, void* stream) {
   VK_CHECK_ARG(c && grads && count > 0, "vk_allreduce_bucket: null argument");
+  if (int rc0 = need_rccl("vk_allreduce_bucket")) return rc0;
   const int rc = rccl().allreduce(grads, grads, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, (hipStream_t)stream);
   return rc == 0 ? VK_OK : nccl_fail("ncclAllReduce", rc);
 }
 
 extern "C" int vk_comm_broadcast(vk_comm* c, void* buf, size_t bytes, int root, void* stream) {
   VK_CHECK_ARG(c && buf && bytes > 0 && root >= 0 && root < c->world, "vk_comm_broadcast: bad argument");
+  if (int rc0 = need_rccl("vk_comm_broadcast")) return rc0;
   const int rc = rccl().broadcast(buf, buf, bytes, /*ncclUint8*/ 1, root, c->comm, (hipStream_t)stream);
   return rc == 0 ? VK_OK : nccl_fail("ncclBroadcast", rc);
 }

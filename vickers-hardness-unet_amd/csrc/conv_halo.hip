@@ -95,6 +95,16 @@ struct HaloCfg {
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 
+// Which halo pixel (of the 64 / 128 a pass covers) thread tid stages; piece = tid & 3.  The 8 lanes that one ds_write_b128 lane group
+// holds are two pixels x four 16-byte pieces: with NEIGHBOURING pixels (96 bytes apart) the second pixel's pieces 2, 3 fall on the
+// banks of the first one's pieces 0, 1 (128-byte bank row of the stores): a 2-way conflict on every halo store, 50 % of their LDS
+// cycles (tools/lds_bank_sim.py).  Pixels p and p + 2 (192 bytes apart) tile the bank row exactly: bits 0 and 1 of the group index
+// are swapped.  A permutation inside aligned groups of four pixels: every pixel is still staged exactly once, by another thread.
+__device__ __forceinline__ int halo_group(int tid) {
+  const int g = tid >> 2;
+  return (g & ~3) | ((g & 1) << 1) | ((g >> 1) & 1);
+}
+
 
 // ---- shared epilogue: accumulators -> LDS [tile pixel][channel] as T -> 16-byte NHWC stores
 //   * optional BN partial sums (sum / sum of squares of the stored values, fp64 atomics into replicated slabs)
@@ -319,11 +329,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
 
   // ---- per-thread staging geometry, computed once (the main loop only adds block-uniform scalars)
   const int hv = tid & 3;                       // 16-byte vector inside the 64-byte pixel chunk (fixed per thread)
+  const int hgrp = halo_group(tid);
   int h_full[NPV], h_half[NPV];                 // pixel index in a full-res / half-res (upsampled) source, -1 = outside
   const int Hh = p.H >> 1, Wh = p.W >> 1;
 #pragma unroll
   for (int i = 0; i < NPV; ++i) {
-    const int hp = (tid >> 2) + i * 64;
+    const int hp = hgrp + i * 64;
     const int hy = hp / 18, hx = hp - hy * 18;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = hp < HPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
   auto store_halo = [&]() {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-      const int hp = (tid >> 2) + i * 64;
+      const int hp = hgrp + i * 64;
       if (hp >= HPIX) continue;
       u32x4_t v = areg[i];
       if (aff) {
@@ -607,11 +618,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
 
   // ---- halo staging geometry (as in the row-staged kernel, NT threads)
   const int hv = tid & 3;
+  const int hgrp = halo_group(tid);
   int h_full[NPV], h_half[NPV];
   const int Hh = p.Hi >> 1, Wh = p.Wi >> 1;
 #pragma unroll
   for (int i = 0; i < NPV; ++i) {
-    const int hp = (tid >> 2) + i * (NT / 4);
+    const int hp = hgrp + i * (NT / 4);
     const int hy = hp / HWI, hx = hp - hy * HWI;
     const int y = STR * y0 - 1 + hy, x = STR * x0 - 1 + hx;
     const bool ok = hp < HPIX && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
@@ -650,7 +662,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_col_kernel(const
   auto store_halo = [&](char* A) {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-      const int hp = (tid >> 2) + i * (NT / 4);
+      const int hp = hgrp + i * (NT / 4);
       if (hp >= HPIX) continue;
       u32x4_t v = areg[i];
       if (aff) {
@@ -862,10 +874,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_s2dg_kernel(const H
   const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
 
   const int hv = tid & 3;
+  const int hgrp = halo_group(tid);
   int h_full[NPV];
 #pragma unroll
   for (int i = 0; i < NPV; ++i) {
-    const int hp = (tid >> 2) + i * (NT / 4);
+    const int hp = hgrp + i * (NT / 4);
     const int hy = hp / RS, hx = hp - hy * RS;
     const int y = y0 + hy, x = x0 + hx;
     const bool ok = hp < HPIX && y < p.Hi && x < p.Wi;
@@ -883,7 +896,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_s2dg_kernel(const H
   auto store_halo = [&](char* A) {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-      const int hp = (tid >> 2) + i * (NT / 4);
+      const int hp = hgrp + i * (NT / 4);
       if (hp < HPIX) *reinterpret_cast<u32x4_t*>(A + hp * APS + hv * 16) = areg[i];
     }
   };
@@ -1033,11 +1046,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_colq_kernel(const H
   const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
 
   const int hv = tid & 3;
+  const int hgrp = halo_group(tid);
   int h_full[NPV], h_half[NPV];
   const int Hh = p.H >> 1, Wh = p.W >> 1;
 #pragma unroll
   for (int i = 0; i < NPV; ++i) {
-    const int hp = (tid >> 2) + i * (NT / 4);
+    const int hp = hgrp + i * (NT / 4);
     const int hy = hp / 18, hx = hp - hy * 18;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = hp < HPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
@@ -1076,7 +1090,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_colq_kernel(const H
   auto store_halo = [&](char* A) {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-      const int hp = (tid >> 2) + i * (NT / 4);
+      const int hp = hgrp + i * (NT / 4);
       if (hp >= HPIX) continue;
       u32x4_t v = areg[i];
       if (aff) {
@@ -1269,11 +1283,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_cols_kernel(const H
   const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
 
   const int hv = tid & 3;
+  const int hgrp = halo_group(tid);
   int h_full[NPV], h_half[NPV];
   const int Hh = p.H >> 1, Wh = p.W >> 1;
 #pragma unroll
   for (int i = 0; i < NPV; ++i) {
-    const int hp = (tid >> 2) + i * (NT / 4);
+    const int hp = hgrp + i * (NT / 4);
     const int hy = hp / 18, hx = hp - hy * 18;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = hp < HPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
@@ -1312,7 +1327,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_cols_kernel(const H
   auto store_halo = [&](char* A) {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-      const int hp = (tid >> 2) + i * (NT / 4);
+      const int hp = hgrp + i * (NT / 4);
       if (hp >= HPIX) continue;
       u32x4_t v = areg[i];
       if (aff) {
@@ -1526,6 +1541,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_colp_kernel(cons
   const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, p.w_bytes);
 
   const int hv = tid & 3;
+  const int hgrp = halo_group(tid);
   const int Hh = p.H >> 1, Wh = p.W >> 1;
   // tile geometry: current tile and the one being prefetched
   struct TileGeo { int n, y0, x0, n0; };
@@ -1544,7 +1560,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_colp_kernel(cons
   auto halo_index = [&](const TileGeo& g, int (&hf)[NPV], int (&hh)[NPV]) {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-      const int hp = (tid >> 2) + i * (NT / 4);
+      const int hp = hgrp + i * (NT / 4);
       const int hy = hp / 18, hx = hp - hy * 18;
       const int y = g.y0 - 1 + hy, x = g.x0 - 1 + hx;
       const bool ok = hp < HPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
@@ -1585,7 +1601,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_colp_kernel(cons
   auto store_halo = [&](char* A, const int (&hf)[NPV]) {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-      const int hp = (tid >> 2) + i * (NT / 4);
+      const int hp = hgrp + i * (NT / 4);
       if (hp >= HPIX) continue;
       u32x4_t v = areg[i];
       if (aff) {
@@ -1864,7 +1880,10 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const HaloParams p) {
 
   // ---- stage halo (2 vectors per pixel) with the BN+ReLU prologue, and all weights of this channel tile
   const bool aff = p.s0.scale != nullptr, relu = p.s0.relu != 0;
-  const int hv = tid & 1;
+  // lane map of the halo staging (r04): 8 consecutive lanes = 8 pixels, the same 16-byte piece — 48-byte pixels put 8 neighbouring
+  // pixels on 8 different 16-byte slots of the 128-byte bank row; (pixel, piece) in thread order gave a 2-way conflict per store
+  const int hv = (tid >> 3) & 1;
+  const int hgrp = (tid & 7) | ((tid >> 4) << 3);
   float sc[VE], sh[VE];
 #pragma unroll
   for (int j = 0; j < VE; ++j) {
@@ -1876,7 +1895,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const HaloParams p) {
   bool aok[NPV];
 #pragma unroll
   for (int i = 0; i < NPV; ++i) {
-    const int hp = (tid >> 1) + i * 128;
+    const int hp = hgrp + i * 128;
     const int hy = hp / 18, hx = hp - hy * 18;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     aok[i] = hp < HPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
@@ -1900,7 +1919,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const HaloParams p) {
   }
 #pragma unroll
   for (int i = 0; i < NPV; ++i) {
-    const int hp = (tid >> 1) + i * 128;
+    const int hp = hgrp + i * 128;
     if (hp >= HPIX) continue;
     u32x4_t v = areg[i];
     if (aff) {

@@ -27,6 +27,10 @@
 #ifndef VK_WH_PIPE
 #define VK_WH_PIPE 0
 #endif
+// -DVK_WH_ZDMA=0: dz of the 64 x 64 tap-split configuration staged through registers + ds_write_b128 as in r03 (A/B builds through VK_LIB)
+#ifndef VK_WH_ZDMA
+#define VK_WH_ZDMA 1
+#endif
 
 namespace vk {
 
@@ -64,7 +68,13 @@ struct WhCfg {
   static constexpr int ZV = KT / VE, VV = CT / VE;
   static constexpr int ZPASS = (PX * ZV + NT - 1) / NT, VPASS = (HPIX * VV + NT - 1) / NT;
   static constexpr int zpad(int ch) { return EB == 2 ? (((ch * 2 / 32) % 2 == 0) ? 32 : 0) : ((ch % 32 == 0) ? 64 : 0); }
-  static constexpr int ZSB = KT * EB + zpad(KT);
+  // ZDMA (r04, the 64 x 64 tap-split 16-bit configuration = the batched kernel): dz needs no operand transform, so its 128 x 64 tile is
+  // written straight into LDS by LDS-DMA (`buffer_load ... lds`: no staging registers, no ds_write, no VALU) as an UNPADDED image of
+  // 128-byte pixel rows whose 32-byte slots are XOR-swizzled with (row >> 1) & 3 — the swizzle sits in the per-lane SOURCE address
+  // (the DMA writes 1 KiB = 8 rows x 8 pieces linearly) and in the transposed fragment reads, which stay conflict-free: the eight
+  // pixel rows one 32-lane group of a ds_read_b64_tr_b16 touches land in eight different 32-byte slots of the 256-byte bank row.
+  static constexpr bool ZDMA = VK_WH_ZDMA && TS && !WS && EB == 2 && STR == 1 && KT == 64;
+  static constexpr int ZSB = ZDMA ? KT * EB : KT * EB + zpad(KT);
   static constexpr int VSB = CT * EB + zpad(CT);
   static constexpr int STAGE = PX * ZSB + HHI * HRS * VSB;
   static constexpr int WK = WS ? KT : KT / 2, WC = WS ? CT : CT / 2;
@@ -103,6 +113,9 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
   const int Hs = p.Hi >> up, Ws = p.Wi >> up;
   const bool affine = sd.scale != nullptr;
   const bool relu = sd.relu != 0;
+  constexpr bool ZDMA = Cfg::ZDMA;
+  static_assert(!(ZDMA && VK_WH_PIPE), "the pipelined fragment reads do not know the swizzled dz image");
+  typedef __attribute__((address_space(3))) void lds_void;
 
   // this thread's V vectors always cover the same channels -> scale/shift once
   float sc[VE], sh[VE];
@@ -135,6 +148,32 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
     z_rel[i] = ((px >> 4) * p.W + (px & 15)) * p.K + k0 + vec * VE;
     z_yx[i] = ok ? (((px >> 4) << 8) | (px & 15)) : -1;
   }
+  // ZDMA: wave w issues the 1 KiB pieces 2 w and 2 w + 1 of the tile (8 pixel rows each); lane l supplies row (l >> 3), LDS piece (l & 7),
+  // i.e. the 8 channels of piece (l & 7) ^ (((row >> 1) & 3) << 1) — (row >> 1) & 3 = (l >> 4) & 3 for every piece (8 rows per piece)
+  const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int zd_rel[2], zd_yx[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (2 * w8 + j) * 8 + (lane >> 3);
+    const int cp = (lane & 7) ^ (((lane >> 4) & 3) << 1);
+    zd_rel[j] = ((row >> 4) * p.W + (row & 15)) * p.K + k0 + cp * VE;
+    zd_yx[j] = (k0 + cp * VE < p.K) ? (((row >> 4) << 8) | (row & 15)) : -1;
+  }
+  auto dma_z = [&](int t, int stage) {            // dz tile t -> the dz image of `stage` (every wave: 2 LDS-DMA instructions)
+    int tt = t;
+    const int tx = tt % p.tiles_x;
+    tt /= p.tiles_x;
+    const int ty = tt % p.tiles_y;
+    const int n = tt / p.tiles_y;
+    const int y0 = ty * 8, x0 = tx * 16;
+    const int zbase = ((n * p.H + y0) * p.W + x0) * p.K;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = zd_yx[j] >= 0 && y0 + (zd_yx[j] >> 8) < p.H && x0 + (zd_yx[j] & 255) < p.W;
+      char* dstp = smem + stage * STAGE + (2 * w8 + j) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsz, (lds_void*)dstp, 16, ok ? (uint32_t)(zbase + zd_rel[j]) * (uint32_t)EB : kOOB, 0, 0, 0);
+    }
+  };
 #pragma unroll
   for (int i = 0; i < VPASS; ++i) {
     const int v = tid + i * NT;
@@ -154,10 +193,12 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
     const int y0 = ty * 8, x0 = tx * 16;
     const int zbase = ((n * p.H + y0) * p.W + x0) * p.K;                                // block-uniform
     const int vbase = ((n * Hs + ((STR * y0) >> up)) * Ws + ((STR * x0) >> up)) * sd.C;
+    if constexpr (!ZDMA) {
 #pragma unroll
-    for (int i = 0; i < ZPASS; ++i) {
-      const bool ok = z_yx[i] >= 0 && y0 + (z_yx[i] >> 8) < p.H && x0 + (z_yx[i] & 255) < p.W;
-      zreg[i] = buf_load16(rsz, ok ? (uint32_t)(zbase + z_rel[i]) * (uint32_t)EB : kOOB);
+      for (int i = 0; i < ZPASS; ++i) {
+        const bool ok = z_yx[i] >= 0 && y0 + (z_yx[i] >> 8) < p.H && x0 + (z_yx[i] & 255) < p.W;
+        zreg[i] = buf_load16(rsz, ok ? (uint32_t)(zbase + z_rel[i]) * (uint32_t)EB : kOOB);
+      }
     }
     vmask = 0;
 #pragma unroll
@@ -172,10 +213,12 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
   auto store_tile = [&](int stage, const u32x4_t (&zreg)[ZPASS], const u32x4_t (&vreg)[VPASS], uint32_t vmask) {
     char* Zs = smem + stage * STAGE;
     char* Vs = Zs + PX * ZSB;
+    if constexpr (!ZDMA) {
 #pragma unroll
-    for (int i = 0; i < ZPASS; ++i) {
-      const int v = tid + i * NT;
-      if (v < PX * ZV) *reinterpret_cast<u32x4_t*>(Zs + (v / ZV) * ZSB + (v % ZV) * 16) = zreg[i];
+      for (int i = 0; i < ZPASS; ++i) {
+        const int v = tid + i * NT;
+        if (v < PX * ZV) *reinterpret_cast<u32x4_t*>(Zs + (v / ZV) * ZSB + (v % ZV) * 16) = zreg[i];
+      }
     }
 #pragma unroll
     for (int i = 0; i < VPASS; ++i) {
@@ -206,7 +249,13 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
 
   typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
   // transposed-read lane geometry: lane j of 16-lane group g supplies pixel 4g + (j>>2), channels 4*(j&3)..+3
-  const int lane_z = (4 * (lane >> 4) + ((lane & 15) >> 2)) * ZSB + (wk0 + 4 * (lane & 3)) * 2;
+  const int lane_z = ZDMA ? (4 * (lane >> 4) + ((lane & 15) >> 2)) * ZSB + 8 * (lane & 3)
+                          : (4 * (lane >> 4) + ((lane & 15) >> 2)) * ZSB + (wk0 + 4 * (lane & 3)) * 2;
+  // ZDMA: the 32-byte slot of channel tile (wk0 / 16 + a) in this lane's pixel rows — row = 16 h + 4 (lane >> 4) + ((lane & 15) >> 2)
+  // (+ 32 ks), so (row >> 1) & 3 depends on the lane alone
+  int zslot[TK];
+#pragma unroll
+  for (int a = 0; a < TK; ++a) zslot[a] = ((((wk0 >> 4) + a) ^ ((2 * (lane >> 4) + ((lane & 15) >> 3)) & 3)) << 5);
   const int lane_v = (4 * (lane >> 4) + ((lane & 15) >> 2)) * VSB + (wc0 + 4 * (lane & 3)) * 2;
 
   // one 32-pixel reduction step = tile rows (2*ks, 2*ks+1)
@@ -221,7 +270,7 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
       u32x4_t zf[TK];
 #pragma unroll
       for (int a = 0; a < TK; ++a) {
-        const char* b0 = Zl + (32 * ks) * ZSB + (a * 16) * 2;
+        const char* b0 = ZDMA ? Zl + zslot[a] + (32 * ks) * ZSB : Zl + (32 * ks) * ZSB + (a * 16) * 2;
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0));
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + 16 * ZSB));
         const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
@@ -352,6 +401,7 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
   int t = t0;
   if (t < t_end) {
     load_tile(t, zreg[0], vreg[0], vmask[0]);
+    if constexpr (ZDMA) dma_z(t, 0);
     store_tile(0, zreg[0], vreg[0], vmask[0]);
   }
   if (DEPTH == 2 && t + t_step < t_end) load_tile(t + t_step, zreg[0], vreg[0], vmask[0]);     // tile 1 -> set 0
@@ -362,7 +412,12 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
       // loads go into set (zl, vl); the set (zs, vs) — requested one (DEPTH 2) or zero (DEPTH 1: same set) iterations ago — is stored
       const bool more = t + t_step < t_end;
       const int tl = t + DEPTH * t_step;
-      if (tl < t_end && !(dbg & 1)) load_tile(tl, zl, vl, ml);
+      if (tl < t_end && !(dbg & 1)) {
+        load_tile(tl, zl, vl, ml);
+        // ZDMA (DEPTH 1): dz of tile t + 1 goes straight into the other stage buffer, which every wave has finished reading (the
+        // barrier that closed the previous iteration); the __syncthreads() closing this one waits for it (vmcnt(0))
+        if constexpr (ZDMA) dma_z(tl, (it + 1) & 1);
+      }
       const char* Zs = smem + (it & 1) * STAGE;
       const char* Vs = Zs + PX * ZSB;
       bool stored = false;
@@ -1178,6 +1233,10 @@ extern "C" int vk_conv_wgrad_batch(const vk_conv_desc* descs, const void* const*
     VK_CHECK_ARG(vk::wgrad_batch_supports(&descs[l]), "vk_conv_wgrad_batch: layer %d is not of the batched class", l);
     VK_CHECK_ARG(descs[l].dtype == descs[0].dtype, "vk_conv_wgrad_batch: mixed element types");
   }
+  // the tables are refilled with synchronous copies below: a previous call's kernels on `stream` may still be READING them (and the
+  // slab) when the caller reuses the buffers, so wait for the stream first (the engine's own batches do the same in
+  // flush_wgrads).  One host wait per call — this entry is the convenience form, the engine keeps a prebuilt plan.
+  VK_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
   vk::WgradBatchPlan plan;
   const int rc = vk::wgrad_batch_build(descs, dz, dw, n, workgroups > 0 ? workgroups : 256 - vkh::reserved_cus(), tables, tables_bytes, &plan);
   if (rc != VK_OK) return rc;
