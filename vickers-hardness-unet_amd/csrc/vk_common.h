@@ -227,6 +227,33 @@ __device__ __forceinline__ u32x4_t buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t
 }
 static constexpr uint32_t kOOB = 0x80000000u;   // any tensor on this path is < 2 GiB (checked on the host)
 
+// ---- LDS-DMA that hipcc does not see (r04).  `__builtin_amdgcn_raw_ptr_buffer_load_lds` is a pending LDS write in the compiler's
+// waitcnt bookkeeping: every later LDS access with a known memory operand (the ds_read_b64_tr_b16 intrinsic among them) gets an
+// `s_waitcnt vmcnt(0)` in front of it, which drains the whole prefetch before the first fragment read of the tile that runs beside it
+// (wgrad_halo_batch_kernel with the builtin: +14 %).  Through inline assembly the instruction is invisible to that pass: the CALLER
+// owns the completion — `lds_dma_wait_all()` before the barrier that publishes the bytes — and nothing else changes for the
+// compiler's own counted waits (the hidden operations are the youngest of the wave when it waits for its register loads, so it can
+// only over-wait; cdna_hip_programming.md section 5.7 item 1).  M0 is saved and restored inside the statement.
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+__device__ __forceinline__ i32x4_t make_rsrc_words(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  i32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));       // stride 0, swizzle off
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+// 64 lanes x 16 bytes -> 1 KiB at LDS byte address lds_addr (wave-uniform); lanes with an out-of-range offset write zeros
+__device__ __forceinline__ void lds_dma16_hidden(i32x4_t srd, uint32_t byte_off, uint32_t lds_addr) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(byte_off), "s"(srd), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ---------------------------------------------------------------- fast division by a runtime constant (n < 2^31)
 struct FastDiv {
   uint32_t mul, shr, div;

@@ -68,7 +68,8 @@ struct WhCfg {
   static constexpr int ZV = KT / VE, VV = CT / VE;
   static constexpr int ZPASS = (PX * ZV + NT - 1) / NT, VPASS = (HPIX * VV + NT - 1) / NT;
   static constexpr int zpad(int ch) { return EB == 2 ? (((ch * 2 / 32) % 2 == 0) ? 32 : 0) : ((ch % 32 == 0) ? 64 : 0); }
-  // ZDMA (r04, the 64 x 64 tap-split 16-bit configuration = the batched kernel): dz needs no operand transform, so its 128 x 64 tile is
+  // ZDMA (r04, the 64 x 64 tap-split 16-bit configuration = the batched kernel; same-box A/B 1.522 -> 1.50 ms per step, after the
+  // loop-carried vmcnt(0) drain described in the tile loop had been removed from both forms: 1.67 -> 1.52): dz needs no operand transform, so its 128 x 64 tile is
   // written straight into LDS by LDS-DMA (`buffer_load ... lds`: no staging registers, no ds_write, no VALU) as an UNPADDED image of
   // 128-byte pixel rows whose 32-byte slots are XOR-swizzled with (row >> 1) & 3 — the swizzle sits in the per-lane SOURCE address
   // (the DMA writes 1 KiB = 8 rows x 8 pieces linearly) and in the transposed fragment reads, which stay conflict-free: the eight
@@ -151,6 +152,8 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
   // ZDMA: wave w issues the 1 KiB pieces 2 w and 2 w + 1 of the tile (8 pixel rows each); lane l supplies row (l >> 3), LDS piece (l & 7),
   // i.e. the 8 channels of piece (l & 7) ^ (((row >> 1) & 3) << 1) — (row >> 1) & 3 = (l >> 4) & 3 for every piece (8 rows per piece)
   const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const i32x4_t rsz_words = make_rsrc_words(p.dz, p.dz_bytes);
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   int zd_rel[2], zd_yx[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -169,9 +172,10 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
     const int zbase = ((n * p.H + y0) * p.W + x0) * p.K;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const bool ok = zd_yx[j] >= 0 && y0 + (zd_yx[j] >> 8) < p.H && x0 + (zd_yx[j] & 255) < p.W;
-      char* dstp = smem + stage * STAGE + (2 * w8 + j) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsz, (lds_void*)dstp, 16, ok ? (uint32_t)(zbase + zd_rel[j]) * (uint32_t)EB : kOOB, 0, 0, 0);
+      const bool ok = (zd_yx[j] >= 0) & (y0 + (zd_yx[j] >> 8) < p.H) & (x0 + (zd_yx[j] & 255) < p.W);
+      const uint32_t dst = smem_base + (uint32_t)(stage * STAGE + (2 * w8 + j) * 1024);
+      // hidden from hipcc (vk_common.h): with the builtin the compiler drains vmcnt(0) in front of the first transposed fragment read
+      lds_dma16_hidden(rsz_words, ok ? (uint32_t)(zbase + zd_rel[j]) * (uint32_t)EB : kOOB, (uint32_t)__builtin_amdgcn_readfirstlane((int)dst));
     }
   };
 #pragma unroll
@@ -196,7 +200,7 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
     if constexpr (!ZDMA) {
 #pragma unroll
       for (int i = 0; i < ZPASS; ++i) {
-        const bool ok = z_yx[i] >= 0 && y0 + (z_yx[i] >> 8) < p.H && x0 + (z_yx[i] & 255) < p.W;
+        const bool ok = (z_yx[i] >= 0) & (y0 + (z_yx[i] >> 8) < p.H) & (x0 + (z_yx[i] & 255) < p.W);      // & : no branches between the loads
         zreg[i] = buf_load16(rsz, ok ? (uint32_t)(zbase + z_rel[i]) * (uint32_t)EB : kOOB);
       }
     }
@@ -204,7 +208,7 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
 #pragma unroll
     for (int i = 0; i < VPASS; ++i) {
       const int y = STR * y0 - 1 + (v_yx[i] >> 8), x = STR * x0 - 1 + (v_yx[i] & 255);
-      const bool ok = v_yx[i] >= 0 && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+      const bool ok = (v_yx[i] >= 0) & ((unsigned)y < (unsigned)p.Hi) & ((unsigned)x < (unsigned)p.Wi);
       vreg[i] = buf_load16(rsv, ok ? (uint32_t)(vbase + v_rel[i]) * (uint32_t)EB : kOOB);
       vmask |= (ok ? 1u : 0u) << i;
     }
@@ -404,6 +408,7 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
     if constexpr (ZDMA) dma_z(t, 0);
     store_tile(0, zreg[0], vreg[0], vmask[0]);
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), known to the compiler (see the tile loop)
   if (DEPTH == 2 && t + t_step < t_end) load_tile(t + t_step, zreg[0], vreg[0], vmask[0]);     // tile 1 -> set 0
   __syncthreads();
   auto tile_loop = [&](auto hsel_c) {
@@ -415,7 +420,7 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
       if (tl < t_end && !(dbg & 1)) {
         load_tile(tl, zl, vl, ml);
         // ZDMA (DEPTH 1): dz of tile t + 1 goes straight into the other stage buffer, which every wave has finished reading (the
-        // barrier that closed the previous iteration); the __syncthreads() closing this one waits for it (vmcnt(0))
+        // barrier that closed the previous iteration); lds_dma_wait_all() in front of the barrier closing this one waits for it
         if constexpr (ZDMA) dma_z(tl, (it + 1) & 1);
       }
       const char* Zs = smem + (it & 1) * STAGE;
@@ -439,6 +444,12 @@ __device__ __forceinline__ void wh_segment(const WhParams& p, char* smem, const 
         }
       }
       if (!stored && more && !(dbg & 2)) store_tile((it + 1) & 1, zs, vs, ms);
+      // every vector-memory operation of this iteration has landed here: the V loads were consumed by store_tile, the hidden dz DMAs
+      // of tile t + 1 were issued in front of this tile's MFMAs.  The wait is the BUILTIN (free at run time) so that hipcc knows it:
+      // without it the loads of the previous iteration count as possibly pending at the loop head (the store is conditional), and the
+      // first reuse of one of their destination registers drew an `s_waitcnt vmcnt(0)` in the middle of the NEXT tile's loads — a full
+      // HBM round trip per tile for the waves of one tap group (r03 binary: ISA of the HSEL = 1 loop)
+      __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0); expcnt / lgkmcnt untouched
       if (!(dbg & 8)) __syncthreads();
     };
     for (int it = 0; t < t_end; t += t_step, ++it) {
