@@ -37,6 +37,10 @@ struct HaloSrc {
   uint32_t bytes;
 };
 
+// -DVK_COLQ_PRE=0: the pipelined K >= 128 kernel's epilogue requests the accumulate / BN-backward operands pass by pass (r03 form)
+#ifndef VK_COLQ_PRE
+#define VK_COLQ_PRE 1
+#endif
 struct HaloParams {
   HaloSrc s0, s1;
   const void* w;
@@ -1229,7 +1233,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_colq_kernel(const H
       }
     return;
   }
-  halo_epilogue<T, TH, BN, TP, TC, NT, (BN <= 64 && TH == 16)>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
+  halo_epilogue<T, TH, BN, TP, TC, NT, (VK_COLQ_PRE || (BN <= 64 && TH == 16))>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
 }
 
 // ---- staggered form of the pipelined kernel (r03): the same tile, operand order and epilogue (bit-identical results), but the two
