@@ -156,6 +156,13 @@ typedef struct {
   const float* scale;
   const float* shift;
   double* sums;
+  /* r04 — the tail of a residual block, out = relu(bn2(z) + shortcut) (reference: torchvision BasicBlock.forward behind train.py:436):
+   * mask != NULL: the ReLU mask is [mask > 0] (mask = the block's stored output, same shape and type as the gradient) instead of
+   * [z*scale+shift > 0]; scale / shift may then be NULL.  accumulate != 0: the convolution result is ADDED to the previous content
+   * of y first (the shortcut gradient that is already there), then masked, summed and stored.  Together they move the BatchNorm
+   * backward reduce of block b into the data gradient of block b+1's conv1, which produces block b's output gradient. */
+  const void* mask;
+  int accumulate;
 } vk_bnr;
 
 /* Data gradient with optional fusions on the first output part (channels [0, split_k1), or all of them):

@@ -472,6 +472,42 @@ def test_conv_dgrad_fused_bn_relu_reduce(dtn, pool2, shape, persist):
     assert torch.allclose(ss[Cc:], (gg * zb.double()).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3 * gg.abs().max().item() * 30)
 
 
+@pytest.mark.parametrize("dtn", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("shape", [(2, 24, 64, 64), (1, 16, 128, 128), (1, 32, 256, 256), (2, 20, 64, 64)], ids=["l1", "l2", "l3", "ragged"])
+def test_conv_dgrad_fused_block_tail(dtn, shape, persist):
+    """vk_bnr with an external mask and accumulate (r04): the data gradient of block b+1's conv1 completes block b's output gradient
+    (it is ADDED to the shortcut gradient already in y), masks it with [out_b > 0] and adds bn2's backward sums, all in its epilogue:
+    y = (dgrad + y_old) * [mask > 0], sums += { sum y, sum y * z }.  Against fp64 autograd of the convolution."""
+    dt = DT[dtn]
+    N, H, Cc, K = shape                                   # Cc: channels of the gradient (conv input), K: conv output channels
+    w = gen(K, Cc, 3, 3, seed=251, scale=0.05)
+    dz = gen(N, K, H, H, seed=252)
+    zb = rnd(gen(N, Cc, H, H, seed=253), dt)               # bn2's raw input z2 of the block below
+    outb = rnd(torch.relu(gen(N, Cc, H, H, seed=254)), dt)  # that block's stored output (about half of it zero)
+    old = rnd(gen(N, Cc, H, H, seed=255), dt)              # the shortcut gradient already in the buffer
+    xin = torch.zeros(N, Cc, H, H, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, rnd(w, dt).double(), padding=1).backward(rnd(dz, dt).double())
+    full = rnd((xin.grad + old.double()).float(), dt)
+    gref = full * (outb > 0)
+    dzd, zbd, outd = to_nhwc(dz, dt), to_nhwc(zb, dt), to_nhwc(outb, dt)
+    wt = D(w.permute(1, 2, 3, 0).contiguous().to(dt))
+    y = to_nhwc(old, dt).clone()
+    sums = torch.zeros(REPL * 2 * Cc, dtype=torch.float64, device=dev())
+    bnr = L_.vk_bnr(zbd.data_ptr(), None, None, sums.data_ptr(), outd.data_ptr(), 1)
+    d = conv_desc(dt, N, H, H, H, H, Cc, 3, 1, 1, 1, mk_src(dzd, K))
+    wp, _ = conv_w(d, wt)
+    rc = vk.lib().vk_conv_dgrad_fused(C.byref(d), wp.data_ptr(), y.data_ptr(), None, 0, 0, C.byref(bnr), st())
+    vk._lib.check(rc)
+    torch.cuda.synchronize()
+    got = from_nhwc(y)
+    assert (got - gref).abs().max().item() <= tol(dt, full) * 1.5
+    assert ((got != 0) & ~(outb > 0)).sum().item() == 0     # the mask is exact: nothing survives where out == 0
+    ss = sums.cpu().view(REPL, 2 * Cc).sum(0)
+    gg = got.double()
+    assert torch.allclose(ss[:Cc], gg.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3 * gg.abs().max().item() * 30)
+    assert torch.allclose(ss[Cc:], (gg * zb.double()).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3 * gg.abs().max().item() * 30)
+
+
 # ------------------------------------------------------------------------------------------------ wgrad
 WGRAD_CASES = [
     ("l1", 2, 24, 64, 64, 3, 1, 1),

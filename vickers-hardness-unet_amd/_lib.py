@@ -32,7 +32,8 @@ class vk_conv_desc(C.Structure):
 
 
 class vk_bnr(C.Structure):
-    _fields_ = [("z", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("sums", C.c_void_p)]
+    _fields_ = [("z", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("sums", C.c_void_p), ("mask", C.c_void_p),
+                ("accumulate", C.c_int)]
 
 
 class vk_letterbox_desc(C.Structure):

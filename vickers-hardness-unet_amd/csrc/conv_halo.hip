@@ -65,6 +65,7 @@ struct HaloParams {
   const float* bnr_scale;
   const float* bnr_shift;
   double* bnr_sums;
+  const void* bnr_mask;         // != nullptr: ReLU mask = [bnr_mask > 0] (a residual block's stored output) instead of the affine of bnr_z
 };
 
 template <typename T, int TH, int BN, int WGM, int WGN>
@@ -145,7 +146,12 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
     }
   __syncthreads();
 
-  const int e_row = tid / EVPR, e_vec = tid % EVPR;
+  // thread -> (tile pixel, 16-byte vector of its channel row).  BN = 128, 16-bit (rows of 272 bytes, 16 vectors): the odd rows take
+  // their vectors rotated by one — the 16-lane groups of a ds_read_b128 then see 16 different 16-byte slots of the 256-byte bank row
+  // (in thread order lanes 12-15 of row r and 20-23 of row r + 1 shared slots: 2-way, tools/lds_bank_sim.py); a per-thread constant
+  // (ERPP is even), so a thread still owns the same 8 channels in every pass
+  const int e_row = tid / EVPR;
+  const int e_vec = (EVPR == 16 && EB == 2) ? (((tid & 15) + ((e_row & 1) ? 15 : 0)) & 15) : tid % EVPR;
   const int col0 = n0 + e_vec * VE;
   const bool col_ok = col0 < p.K;
   char* yb = (char*)p.y0;
@@ -156,15 +162,16 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
 #pragma unroll
   for (int j = 0; j < VE; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   const bool bnr = p.bnr_z != nullptr && first_part && col_ok;
+  const bool ext_mask = p.bnr_mask != nullptr;               // block-tail form (vk_bnr.mask)
   float bsc[VE], bsh[VE];
-  if (bnr) {
+  if (bnr && !ext_mask) {
 #pragma unroll
     for (int j = 0; j < VE; ++j) { bsc[j] = p.bnr_scale[colx + j]; bsh[j] = p.bnr_shift[colx + j]; }
   }
   // final value of one output vector: optional accumulate, optional BN+ReLU-backward masking + sums, store
   // pre_old / pre_z: the destination's previous content (accumulate) and the matching vector of bnr_z when the caller has
   // requested them ahead (PRE below); otherwise they are loaded here
-  auto finish = [&](float (&f)[VE], size_t elem_off, const u32x4_t* pre_old, const u32x4_t* pre_z) {
+  auto finish = [&](float (&f)[VE], size_t elem_off, const u32x4_t* pre_old, const u32x4_t* pre_z, const u32x4_t* pre_m = nullptr) {
     u32x4_t* gp = reinterpret_cast<u32x4_t*>(yb + elem_off * EB);
     if (p.accumulate) {
       float o[VE];
@@ -177,9 +184,19 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
     if (bnr) {
       float zf[VE];
       Vec16<T>::unpack(pre_z ? *pre_z : *reinterpret_cast<const u32x4_t*>((const char*)p.bnr_z + elem_off * EB), zf);
+      if (ext_mask) {
+        float mf[VE];
+        Vec16<T>::unpack(pre_m ? *pre_m : *reinterpret_cast<const u32x4_t*>((const char*)p.bnr_mask + elem_off * EB), mf);
+#pragma unroll
+        for (int j = 0; j < VE; ++j)
+          if (!(mf[j] > 0.f)) f[j] = 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < VE; ++j)
+          if (!(fmaf(zf[j], bsc[j], bsh[j]) > 0.f)) f[j] = 0.f;
+      }
 #pragma unroll
       for (int j = 0; j < VE; ++j) {
-        if (!(fmaf(zf[j], bsc[j], bsh[j]) > 0.f)) f[j] = 0.f;
         s1[j] += f[j];
         s2[j] += f[j] * zf[j];
       }
@@ -215,7 +232,7 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
     // PRE: request the accumulate / bnr operands of all EPASS vectors before the first one is finished (one memory round
     // trip instead of EPASS; pays on the 64-channel tiles with 8 passes per thread: L1 data gradient + reduce 73 -> 70 us,
     // costs registers, hence occupancy, on the C = 16 kernels: off there)
-    u32x4_t oldv[PRE ? EPASS : 1], zv[PRE ? EPASS : 1];
+    u32x4_t oldv[PRE ? EPASS : 1], zv[PRE ? EPASS : 1], mv[PRE ? EPASS : 1];
     if (PRE && (p.accumulate || bnr)) {
 #pragma unroll
       for (int ps = 0; ps < (PRE ? EPASS : 0); ++ps) {
@@ -223,10 +240,12 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
         const int y = OS * (y0 + (row >> 4)) + py, x = OS * (x0 + (row & 15)) + px;
         oldv[ps] = u32x4_t{0, 0, 0, 0};
         zv[ps] = u32x4_t{0, 0, 0, 0};
+        mv[ps] = u32x4_t{0, 0, 0, 0};
         if (y < p.H && x < p.W && col_ok) {
           const size_t eoff = (((size_t)n * p.H + y) * p.W + x) * ld + colx;
           if (p.accumulate) oldv[ps] = *reinterpret_cast<const u32x4_t*>(yb + eoff * EB);
           if (bnr) zv[ps] = *reinterpret_cast<const u32x4_t*>((const char*)p.bnr_z + eoff * EB);
+          if (bnr && ext_mask) mv[ps] = *reinterpret_cast<const u32x4_t*>((const char*)p.bnr_mask + eoff * EB);
         }
       }
     }
@@ -240,7 +259,7 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
         float f[VE];
         if (p.accumulate || bnr) {
           Vec16<T>::unpack(raw, f);
-          if (PRE) finish(f, eoff, &oldv[ps], &zv[ps]);
+          if (PRE) finish(f, eoff, &oldv[ps], &zv[ps], &mv[ps]);
           else finish(f, eoff, nullptr, nullptr);
         } else {
           // plain store: the LDS tile already holds the rounded values, so they go out as they are (no pack / unpack round
@@ -279,8 +298,8 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
       const int slot = (wave * 4 + kg) / RPS;
 #pragma unroll
       for (int j = 0; j < VE; ++j) {
-        red[(slot * BN + (lane % EVPR) * VE + j) * 2 + 0] = s1[j];
-        red[(slot * BN + (lane % EVPR) * VE + j) * 2 + 1] = s2[j];
+        red[(slot * BN + e_vec * VE + j) * 2 + 0] = s1[j];
+        red[(slot * BN + e_vec * VE + j) * 2 + 1] = s2[j];
       }
     }
     __syncthreads();
@@ -2071,14 +2090,25 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const HaloParams p)
 #pragma unroll
   for (int q = 0; q < NLD; ++q) {
     const int v = lane + 64 * q;
-    const int hx = v / VPP, hv = v % VPP;
+    // lane -> (staged pixel, 16-byte piece): inside complete groups the order that keeps the 8 lanes of a ds_write_b128 lane group on 8
+    // different 16-byte slots of the 128-byte bank row (see halo_group: 96-byte pixels pair p with p + 2, 48-byte pixels take 8
+    // neighbouring pixels with the same piece); the incomplete last group keeps thread order
+    int hx = v / VPP, hv = v % VPP;
+    if (VPP == 4) {
+      if ((hx | 3) < Cfg::NPX) hx = (hx & ~3) | ((hx & 1) << 1) | ((hx >> 1) & 1);
+    } else {
+      if ((v | 15) < NVEC) { hx = (v & 7) | ((v >> 4) << 3); hv = (v >> 3) & 1; }
+    }
     const int xs = (UP ? (x0 >> 1) : x0) - 1 + hx;
     xok[q] = v < NVEC && (unsigned)xs < (unsigned)Ws;
     ld_col[q] = xs * CIN + hv * VE;
     st_off[q] = v < NVEC ? hx * APS + hv * 16 : -1;
   }
   if (MODE == 0) {
-    const int hv = lane % VPP;                       // 64 % VPP == 0: both vectors of a lane cover the same channels
+    // the channels of this lane's vector(s): VPP = 4: piece lane % 4 for both (64 % 4 == 0, the pixel permutation leaves the piece
+    // alone); VPP = 2: one vector per lane (NLD == 1), its piece follows the lane map above
+    static_assert(VPP == 4 || NLD == 1, "C = 16: one staged vector per lane");
+    const int hv = VPP == 4 ? lane % VPP : (((lane | 15) < NVEC) ? (lane >> 3) & 1 : lane % VPP);
 #pragma unroll
     for (int j = 0; j < VE; ++j) {
       sc[j] = aff ? p.s0.scale[hv * VE + j] : 1.f;
@@ -2943,8 +2973,10 @@ int conv3x3_halo_try(const vk_conv_desc* d, const void* w, int packed, void* y, 
   p.bnr_scale = bnr ? bnr->scale : nullptr;
   p.bnr_shift = bnr ? bnr->shift : nullptr;
   p.bnr_sums = bnr ? bnr->sums : nullptr;
+  p.bnr_mask = bnr ? bnr->mask : nullptr;
   p.nchunks = c16 ? 1 : C / ck;
-  if (eb == 2 && !s2 && !s2d && (c16 || C == 32)) {      // small-channel decoder layers: the streaming kernel where it covers the launch
+  if (p.bnr_mask && (c16 || s2 || s2d || pool2)) return VK_ERR_UNSUPPORTED;      // the block-tail form lives in the stride-1 tile epilogue only
+  if (eb == 2 && !s2 && !s2d && !p.bnr_mask && (c16 || C == 32)) {      // small-channel decoder layers: the streaming kernel where it covers the launch
     const int rc = d->dtype == VK_BF16 ? stream_try<bf16_t>(p, st) : stream_try<f16_t>(p, st);
     if (rc != VK_ERR_UNSUPPORTED) return rc;
   }

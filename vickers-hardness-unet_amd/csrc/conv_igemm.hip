@@ -649,8 +649,9 @@ extern "C" int vk_conv_dgrad_pool2(const vk_conv_desc* d, const void* w, void* y
 
 extern "C" int vk_conv_dgrad_fused(const vk_conv_desc* d, const void* w, void* y, void* y1, int split_k1, int pool2, const vk_bnr* bnr,
                                    void* stream) {
-  VK_CHECK_ARG(!bnr || (bnr->z && bnr->scale && bnr->shift && bnr->sums), "vk_conv_dgrad_fused: incomplete vk_bnr");
-  return vk::conv_fwd_impl(d, w, vk::is_c16(d) ? 0 : 1, y, y1, split_k1, 0, nullptr, pool2, bnr, (hipStream_t)stream);
+  VK_CHECK_ARG(!bnr || (bnr->z && bnr->sums && (bnr->mask || (bnr->scale && bnr->shift))), "vk_conv_dgrad_fused: incomplete vk_bnr");
+  VK_CHECK_ARG(!bnr || !(bnr->mask && pool2), "vk_conv_dgrad_fused: the external mask does not combine with pool2");
+  return vk::conv_fwd_impl(d, w, vk::is_c16(d) ? 0 : 1, y, y1, split_k1, bnr ? bnr->accumulate : 0, nullptr, pool2, bnr, (hipStream_t)stream);
 }
 
 extern "C" int vk_conv_fwd_packed(const vk_conv_desc* d, const void* w_halo, void* y, void* y1, int split_k1, int accumulate, double* stats,

@@ -389,6 +389,7 @@ struct vk_unet {
   std::vector<HaloPackEntry> halo_tab;
   std::vector<size_t> off_z, off_g, off_out, off_gout;
   std::vector<char> g_prereduced;      // per conv: its gradient buffer already holds masked g + sums (vk_bnr fusion)
+  std::vector<char> tail_prereduced;   // per block: gout already holds g = gout * [out > 0] and bn2's sums are complete (vk_bnr.mask fusion)
   // bound pointers
   float* params = nullptr;
   float* grads = nullptr;
@@ -581,6 +582,7 @@ void layout_workspace(vk_unet* h) {
   };
   h->off_x4 = take((size_t)N * S * S * 4 * eb);
   h->g_prereduced.assign(h->convs.size(), 0);
+  h->tail_prereduced.assign(h->blocks.size(), 0);
   h->off_z.resize(h->convs.size());
   h->off_g.assign(h->convs.size(), 0);
   for (size_t i = 0; i < h->convs.size(); ++i) {
@@ -1097,7 +1099,7 @@ int conv_wgrad(vk_unet* h, ConvL& c, const vk_src& s0, const vk_src& s1, hipStre
 vk_bnr bnr_of(vk_unet* h, ConvL& target) {     // fused BN+ReLU backward reduce descriptor for the layer `target`
   BnL& b = h->bns[target.bn];
   vk_bnr r;
-  r.z = target.z; r.scale = b.scale; r.shift = b.shift; r.sums = b.bsums;
+  r.z = target.z; r.scale = b.scale; r.shift = b.shift; r.sums = b.bsums; r.mask = nullptr; r.accumulate = 0;
   return r;
 }
 
@@ -1217,20 +1219,25 @@ int backward_block(vk_unet* h, int bi, hipStream_t st) {
     xin = Act{pb.out, pb.C, nullptr, nullptr, 0};
     gin = pb.gout;
   }
-  // tail: out = relu(bn2(z2) + shortcut);  g = gout * (out > 0)
-  RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.bsums, st));
+  // tail: out = relu(bn2(z2) + shortcut);  g = gout * (out > 0).  r04: when the NEXT block is an identity block, the data gradient of
+  // its conv1 — the kernel that completes this block's gout — has already masked it with [out > 0] and added bn2's sums (vk_bnr.mask,
+  // see below): no reduce pass here and the apply passes read g as it stands (mask mode 0: one tensor read less each)
+  const bool pre = h->tail_prereduced[(size_t)bi] != 0;
+  h->tail_prereduced[(size_t)bi] = 0;
+  const int mm = pre ? 0 : 2;
+  if (!pre) RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.bsums, st));
   if (k.convd < 0) {
     // identity shortcut: gin (+)= g
     RET_IF(vk_bn_bwd_coeffs(k.C, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd, h->grads + b2.g_off, h->grads + b2.b_off, b2.coef, st));
-    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.coef, c2.g, gin, k.in_has_grad_first ? 1 : 0, st));
+    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, mm, nullptr, nullptr, k.out, b2.coef, c2.g, gin, k.in_has_grad_first ? 1 : 0, st));
   } else {
     ConvL& cd = h->convs[k.convd];
     BnL& bd = h->bns[cd.bn];
     RET_IF(vk_bn_bwd_coeffs(k.C, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd, h->grads + b2.g_off, h->grads + b2.b_off, b2.coef, st));
-    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.coef, c2.g, nullptr, 0, st));
-    RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, cd.z, 2, nullptr, nullptr, k.out, bd.bsums, st));
+    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, mm, nullptr, nullptr, k.out, b2.coef, c2.g, nullptr, 0, st));
+    RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, cd.z, mm, nullptr, nullptr, k.out, bd.bsums, st));
     RET_IF(vk_bn_bwd_coeffs(k.C, bd.bsums, bd.count, h->params + bd.g_off, bd.mean, bd.invstd, h->grads + bd.g_off, h->grads + bd.b_off, bd.coef, st));
-    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, cd.z, 2, nullptr, nullptr, k.out, bd.coef, cd.g, nullptr, 0, st));
+    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, cd.z, mm, nullptr, nullptr, k.out, bd.coef, cd.g, nullptr, 0, st));
   }
   // conv2 (data gradient first, weight gradient after it: see backward_decoder)
   bool fused1 = false;
@@ -1239,7 +1246,22 @@ int backward_block(vk_unet* h, int bi, hipStream_t st) {
   // conv1
   RET_IF(bn_relu_bwd_inplace(h, c1, fused1, st));
   // gin was written by the identity shortcut above or (downsample blocks) by the decoder skip gradient
-  RET_IF(conv_dgrad(h, c1, gin, nullptr, 0, 1, st));
+  // Identity block behind another block: this data gradient COMPLETES the output gradient of block bi - 1 (gin = its gout), so its
+  // epilogue applies that block's tail — mask [out > 0], sums of g and g * z2 for bn2 — while the vectors are in registers: the
+  // separate reduce pass (3 tensor reads) and the mask reads of the apply passes go (train.py:443/:448: autograd's relu / add /
+  // batch_norm backward nodes of torchvision's BasicBlock).  Downsample blocks finish gin with their 1x1 data gradient: not fused.
+  bool tail_fused = false;
+  if (k.convd < 0 && bi > 0 && c1.halo_dg && !getenv("VK_NO_TAIL_BNR_FUSION")) {
+    BlockL& pb = h->blocks[bi - 1];
+    ConvL& pc2 = h->convs[pb.conv2];
+    vk_conv_desc dd = dgrad_desc(h, c1);
+    vk_bnr r;
+    r.z = pc2.z; r.scale = nullptr; r.shift = nullptr; r.sums = h->bns[pc2.bn].bsums; r.mask = pb.out; r.accumulate = 1;
+    const int rc = vk_conv_dgrad_fused(&dd, dgrad_weights(h, c1), gin, nullptr, 0, 0, &r, st);
+    if (rc == VK_OK) { tail_fused = true; h->tail_prereduced[(size_t)bi - 1] = 1; }
+    else if (rc != VK_ERR_UNSUPPORTED) return rc;
+  }
+  if (!tail_fused) RET_IF(conv_dgrad(h, c1, gin, nullptr, 0, 1, st));
   if (k.convd >= 0) {
     ConvL& cd = h->convs[k.convd];
     RET_IF(conv_dgrad(h, cd, gin, nullptr, 0, 1, st));
