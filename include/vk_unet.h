@@ -432,9 +432,11 @@ int vk_adamw_step_amp(size_t n, float* param, const float* grad, float* exp_avg,
 typedef struct vk_unet vk_unet;
 
 typedef struct {
-  int N, size;          /* batch per GPU and square input size (size % 32 == 0) */
+  int N, size;          /* batch per GPU and input HEIGHT (size % 32 == 0) */
   vk_dtype dtype;       /* compute/storage type of activations: VK_F32 (exact path) or VK_BF16 / VK_F16 */
   int training;         /* 1: plan keeps everything backward needs */
+  int width;            /* input WIDTH (width % 32 == 0); 0 = size, the square inputs every reference script produces (train.py:70-75,
+                           infer_pth_gui.py:17-24 letterbox to img_size x img_size) — smp itself accepts any H, W divisible by 32 (r04) */
 } vk_unet_config;
 
 typedef struct {

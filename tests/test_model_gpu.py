@@ -63,6 +63,52 @@ def test_eval_logits_fp32(pair, n, s):
     assert abs(vk.dice_coef(pg.to(dev()), y.to(dev())) - O.dice_coef(pg, y)) <= 1e-6
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 64, 96), (1, 160, 64), (1, 96, 224)])
+def test_non_square_inputs_vs_oracle(pair, n, h, w):
+    """smp's Unet accepts any height and width divisible by 32 (the reference's scripts always letterbox to a square: train.py:70-75,
+    infer_pth_gui.py:17-24); r04: so does the engine.  fp32 eval logits, 16-bit eval logits against the CPU-autocast yardstick, and
+    one fp32 training step (loss, BatchNorm running mean, the extreme gradients of the network) against the oracle."""
+    O, _, _ = pair
+    O.set_seed(42)
+    ref = O.build_model()
+    O.set_seed(42)
+    model = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev())
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, 3, h, w, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    y = (((yy - h * 0.45).abs() / h + (xx - w * 0.55).abs() / w) < 0.22).float().expand(n, 1, h, w).contiguous()
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        lo = ref(x)
+        lg = model(x.to(dev())).cpu()
+    assert lg.shape == (n, 1, h, w)
+    assert (lg - lo).abs().max().item() <= 1e-3
+    assert abs(O.iou_coef(torch.sigmoid(lg), y) - O.iou_coef(torch.sigmoid(lo), y)) <= 1e-4
+    for dtype in (torch.bfloat16, torch.float16):
+        yard = (_oracle_eval(ref, x, dtype) - lo).abs()
+        model.compute_dtype = dtype
+        with torch.no_grad():
+            e = (model(x.to(dev())).float().cpu() - lo).abs()
+        assert e.max().item() <= 1.5 * yard.max().item() + 1e-3 and e.mean().item() <= 1.5 * yard.mean().item() + 1e-4, (dtype, e.max(), yard.max())
+    model.compute_dtype = torch.float32
+    # one training step
+    ref.train(); model.train()
+    opt_r = torch.optim.AdamW(ref.parameters(), lr=5e-5, weight_decay=1e-4)
+    opt_g = vk.adamw_for(model, lr=5e-5, weight_decay=1e-4)
+    loss_r = O.train_steps(ref, opt_r, [(x, y)])[0]
+    opt_g.zero_grad(set_to_none=True)
+    out = model.loss_and_backward(x.to(dev()), y.to(dev()))
+    grads = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()}
+    opt_g.step()
+    assert out[0].item() == pytest.approx(loss_r, rel=2e-3)
+    rg = {k: p.grad for k, p in ref.named_parameters()}
+    for k in ("encoder.conv1.weight", "encoder.layer2.0.downsample.0.weight", "encoder.layer4.2.conv2.weight", "decoder.blocks.0.conv1.0.weight",
+              "decoder.blocks.4.conv2.0.weight", "segmentation_head.0.weight", "segmentation_head.0.bias", "encoder.layer3.1.bn2.weight"):
+        a, b = grads[k].double(), rg[k].double()
+        assert (a - b).norm().item() <= 2e-2 * b.norm().item() + 1e-9, k          # relative L2, the bar of the fp32 gradient tests
+    assert (model.state_dict()["encoder.bn1.running_mean"].cpu() - ref.encoder.bn1.running_mean).abs().max().item() <= 1e-4
+
+
 def _engine_relu_masks(ref, model, n, s):
     """The ReLU decisions the engine took in its last training forward, keyed by the oracle's nn.ReLU module name, in call
     order (a BasicBlock calls its ReLU twice: after bn1 and on the block tail).  Bool NCHW CPU tensors."""

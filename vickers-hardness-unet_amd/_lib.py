@@ -65,7 +65,7 @@ class vk_aug_params(C.Structure):
 
 
 class vk_unet_config(C.Structure):
-    _fields_ = [("N", C.c_int), ("size", C.c_int), ("dtype", C.c_int), ("training", C.c_int)]
+    _fields_ = [("N", C.c_int), ("size", C.c_int), ("dtype", C.c_int), ("training", C.c_int), ("width", C.c_int)]
 
 
 class vk_tensor_info(C.Structure):

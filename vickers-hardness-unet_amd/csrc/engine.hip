@@ -316,7 +316,8 @@ struct ConvL {
   bool halo_fwd = false;  // forward runs on the 3x3 tile kernels and reads the halo pack of its weights
   bool halo_dg = false;   // same for the data gradient (the dgrad arena slot then holds the pack instead of plain [C][RS][K])
   int bn;                 // following BN (-1 for the head)
-  int Hin, Hout;          // square spatial sizes
+  int Hin, Hout;          // spatial sizes: rows ...
+  int Win, Wout;          // ... and columns (r04: H != W allowed, both divisible by 32)
   // workspace
   char* z = nullptr;      // raw conv output [N][Hout][Hout][K]
   char* g = nullptr;      // gradient wrt activated output, overwritten in place by gradient wrt z
@@ -341,7 +342,7 @@ struct BnL {
 
 struct BlockL {
   int conv1, conv2, convd;      // convd = -1 for identity shortcut
-  int Cin, C, stride, Hin, Hout;
+  int Cin, C, stride, Hin, Hout, Win, Wout;
   bool in_has_grad_first;       // gradient buffer of the block input was already written (skip feature)
   char* out = nullptr;
   char* gout = nullptr;
@@ -349,7 +350,7 @@ struct BlockL {
 
 struct DecL {
   int conv1, conv2;
-  int Cup, Cskip, Cout, H;      // H = output resolution
+  int Cup, Cskip, Cout, H, W;   // H x W = output resolution
 };
 
 struct Act {                     // a (possibly virtual) activated tensor
@@ -444,12 +445,13 @@ void add_info(vk_unet* h, const std::string& name, int kind, std::vector<int> di
   h->infos.push_back(ti);
 }
 
-int add_conv(vk_unet* h, const std::string& name, int Cin, int K, int R, int stride, int pad, int Hin, bool bias = false) {
+int add_conv(vk_unet* h, const std::string& name, int Cin, int K, int R, int stride, int pad, int Hin, int Win, bool bias = false) {
   ConvL c;
   c.name = name;
   c.Cin = Cin; c.K = K; c.R = R; c.stride = stride; c.pad = pad;
-  c.Hin = Hin;
+  c.Hin = Hin; c.Win = Win;
   c.Hout = (Hin + 2 * pad - R) / stride + 1;
+  c.Wout = (Win + 2 * pad - R) / stride + 1;
   c.w_off = h->n_params;
   c.wd_off = -1;
   c.bn = -1;
@@ -488,15 +490,15 @@ int add_bn(vk_unet* h, const std::string& name, int C, double count) {
 }
 
 void build_topology(vk_unet* h) {
-  const int S = h->cfg.size, N = h->cfg.N;
-  auto cnt = [&](int Hres) { return (double)N * Hres * Hres; };
+  const int S = h->cfg.size, SW = h->cfg.width, N = h->cfg.N;
+  auto cnt = [&](int Hres, int Wres) { return (double)N * Hres * Wres; };
   // --- encoder stem
-  h->stem_conv = add_conv(h, "encoder.conv1", 3, 64, 7, 2, 3, S);
-  h->convs[h->stem_conv].bn = add_bn(h, "encoder.bn1", 64, cnt(S / 2));
+  h->stem_conv = add_conv(h, "encoder.conv1", 3, 64, 7, 2, 3, S, SW);
+  h->convs[h->stem_conv].bn = add_bn(h, "encoder.bn1", 64, cnt(S / 2, SW / 2));
   // --- encoder layers
   const int nblocks[4] = {3, 4, 6, 3};
   const int planes[4] = {64, 128, 256, 512};
-  int inpl = 64, res = S / 4;
+  int inpl = 64, res = S / 4, resw = SW / 4;
   std::vector<int64_t> layer_start(4), layer3_mid(1);
   std::vector<int64_t> block_start;
   for (int L = 0; L < 4; ++L) {
@@ -506,21 +508,22 @@ void build_topology(vk_unet* h) {
       const int stride = (b == 0 && L > 0) ? 2 : 1;
       const std::string pre = "encoder.layer" + std::to_string(L + 1) + "." + std::to_string(b);
       BlockL blk;
-      blk.Cin = inpl; blk.C = planes[L]; blk.stride = stride; blk.Hin = res; blk.Hout = res / stride;
-      blk.conv1 = add_conv(h, pre + ".conv1", inpl, planes[L], 3, stride, 1, res);
-      h->convs[blk.conv1].bn = add_bn(h, pre + ".bn1", planes[L], cnt(blk.Hout));
-      blk.conv2 = add_conv(h, pre + ".conv2", planes[L], planes[L], 3, 1, 1, blk.Hout);
-      h->convs[blk.conv2].bn = add_bn(h, pre + ".bn2", planes[L], cnt(blk.Hout));
+      blk.Cin = inpl; blk.C = planes[L]; blk.stride = stride; blk.Hin = res; blk.Hout = res / stride; blk.Win = resw; blk.Wout = resw / stride;
+      blk.conv1 = add_conv(h, pre + ".conv1", inpl, planes[L], 3, stride, 1, res, resw);
+      h->convs[blk.conv1].bn = add_bn(h, pre + ".bn1", planes[L], cnt(blk.Hout, blk.Wout));
+      blk.conv2 = add_conv(h, pre + ".conv2", planes[L], planes[L], 3, 1, 1, blk.Hout, blk.Wout);
+      h->convs[blk.conv2].bn = add_bn(h, pre + ".bn2", planes[L], cnt(blk.Hout, blk.Wout));
       blk.convd = -1;
       if (stride != 1 || inpl != planes[L]) {
-        blk.convd = add_conv(h, pre + ".downsample.0", inpl, planes[L], 1, stride, 0, res);
-        h->convs[blk.convd].bn = add_bn(h, pre + ".downsample.1", planes[L], cnt(blk.Hout));
+        blk.convd = add_conv(h, pre + ".downsample.0", inpl, planes[L], 1, stride, 0, res, resw);
+        h->convs[blk.convd].bn = add_bn(h, pre + ".downsample.1", planes[L], cnt(blk.Hout, blk.Wout));
       }
       // the input of block 0 of layers 2-4 is a skip feature whose gradient the decoder wrote first
       blk.in_has_grad_first = (b == 0 && L > 0);
       h->blocks.push_back(blk);
       inpl = planes[L];
       res = blk.Hout;
+      resw = blk.Wout;
     }
     h->layer_last_block[L] = (int)h->blocks.size() - 1;
   }
@@ -529,23 +532,24 @@ void build_topology(vk_unet* h) {
   const int dec_skip[5] = {256, 128, 64, 64, 0};
   const int dec_out[5] = {256, 128, 64, 32, 16};
   std::vector<int64_t> dec_start(5);
-  int dres = S / 32;
+  int dres = S / 32, dresw = SW / 32;
   for (int i = 0; i < 5; ++i) {
     dec_start[i] = h->n_params;
     dres *= 2;
+    dresw *= 2;
     const std::string pre = "decoder.blocks." + std::to_string(i);
     DecL d;
-    d.Cup = dec_in[i]; d.Cskip = dec_skip[i]; d.Cout = dec_out[i]; d.H = dres;
-    d.conv1 = add_conv(h, pre + ".conv1.0", dec_in[i] + dec_skip[i], dec_out[i], 3, 1, 1, dres);
-    h->convs[d.conv1].bn = add_bn(h, pre + ".conv1.1", dec_out[i], cnt(dres));
-    d.conv2 = add_conv(h, pre + ".conv2.0", dec_out[i], dec_out[i], 3, 1, 1, dres);
-    h->convs[d.conv2].bn = add_bn(h, pre + ".conv2.1", dec_out[i], cnt(dres));
+    d.Cup = dec_in[i]; d.Cskip = dec_skip[i]; d.Cout = dec_out[i]; d.H = dres; d.W = dresw;
+    d.conv1 = add_conv(h, pre + ".conv1.0", dec_in[i] + dec_skip[i], dec_out[i], 3, 1, 1, dres, dresw);
+    h->convs[d.conv1].bn = add_bn(h, pre + ".conv1.1", dec_out[i], cnt(dres, dresw));
+    d.conv2 = add_conv(h, pre + ".conv2.0", dec_out[i], dec_out[i], 3, 1, 1, dres, dresw);
+    h->convs[d.conv2].bn = add_bn(h, pre + ".conv2.1", dec_out[i], cnt(dres, dresw));
     h->decs.push_back(d);
   }
   // --- head
   const int64_t head_start = h->n_params;
   (void)head_start;
-  h->head_conv = add_conv(h, "segmentation_head.0", 16, 1, 3, 1, 1, S, /*bias=*/true);
+  h->head_conv = add_conv(h, "segmentation_head.0", 16, 1, 3, 1, 1, S, SW, /*bias=*/true);
   h->head_w_off = h->convs[h->head_conv].w_off;
   h->head_b_off = h->head_w_off + 144;
   h->n_params = (int64_t)align_up((size_t)h->n_params, 64);
@@ -572,7 +576,7 @@ void build_topology(vk_unet* h) {
 }
 
 void layout_workspace(vk_unet* h) {
-  const int N = h->cfg.N, S = h->cfg.size, eb = h->eb;
+  const int N = h->cfg.N, S = h->cfg.size, SW = h->cfg.width, eb = h->eb;
   const bool tr = h->cfg.training != 0;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -580,7 +584,7 @@ void layout_workspace(vk_unet* h) {
     off = align_up(off + bytes, 256);
     return o;
   };
-  h->off_x4 = take((size_t)N * S * S * 4 * eb);
+  h->off_x4 = take((size_t)N * S * SW * 4 * eb);
   h->g_prereduced.assign(h->convs.size(), 0);
   h->tail_prereduced.assign(h->blocks.size(), 0);
   h->off_z.resize(h->convs.size());
@@ -588,26 +592,26 @@ void layout_workspace(vk_unet* h) {
   for (size_t i = 0; i < h->convs.size(); ++i) {
     const ConvL& c = h->convs[i];
     if ((int)i == h->head_conv) { h->off_z[i] = 0; continue; }
-    const size_t bytes = (size_t)N * c.Hout * c.Hout * c.K * eb;
+    const size_t bytes = (size_t)N * c.Hout * c.Wout * c.K * eb;
     h->off_z[i] = take(bytes);
     if (tr) h->off_g[i] = take(bytes);
   }
-  h->off_pool = take((size_t)N * (S / 4) * (S / 4) * 64 * eb);
-  h->off_argmax = take((size_t)N * (S / 4) * (S / 4) * 64);
-  if (tr) h->off_gpool = take((size_t)N * (S / 4) * (S / 4) * 64 * eb);
+  h->off_pool = take((size_t)N * (S / 4) * (SW / 4) * 64 * eb);
+  h->off_argmax = take((size_t)N * (S / 4) * (SW / 4) * 64);
+  if (tr) h->off_gpool = take((size_t)N * (S / 4) * (SW / 4) * 64 * eb);
   h->off_out.resize(h->blocks.size());
   h->off_gout.assign(h->blocks.size(), 0);
   for (size_t b = 0; b < h->blocks.size(); ++b) {
     const BlockL& k = h->blocks[b];
-    const size_t bytes = (size_t)N * k.Hout * k.Hout * k.C * eb;
+    const size_t bytes = (size_t)N * k.Hout * k.Wout * k.C * eb;
     h->off_out[b] = take(bytes);
     if (tr) h->off_gout[b] = take(bytes);
   }
   if (tr) {
     size_t mx = 0;
-    for (const DecL& d : h->decs) mx = std::max(mx, (size_t)N * d.H * d.H * d.Cup * eb);
+    for (const DecL& d : h->decs) mx = std::max(mx, (size_t)N * d.H * d.W * d.Cup * eb);
     h->off_dup = take(mx);
-    h->off_dlogits = take((size_t)N * S * S * 4);
+    h->off_dlogits = take((size_t)N * S * SW * 4);
   }
   h->off_loss_sums = take(8 * sizeof(double));
   // per-BN statistics (one zero region) and float arena
@@ -630,7 +634,7 @@ void layout_workspace(vk_unet* h) {
   h->off_wslab = tr ? take(kEngineSlabBytes) : 0;
   h->off_tab_wbatch = tr ? take((size_t)kMaxStages * 2 * VK_WGRAD_BATCH_TABLE_BYTES) : 0;
   // eval plans with few tiles per layer (batch-1 inference) split the channel reduction: scratch for the partial tiles
-  h->splitk_bytes = (!tr && (size_t)N * S * S <= 4u * 512 * 512) ? VK_SPLITK_WORKSPACE_BYTES : 0;
+  h->splitk_bytes = (!tr && (size_t)N * S * SW <= 4u * 512 * 512) ? VK_SPLITK_WORKSPACE_BYTES : 0;
   h->off_splitk = h->splitk_bytes ? take(h->splitk_bytes) : 0;
   h->off_tab_pack = take(h->convs.size() * sizeof(PackEntry));
   h->off_tab_cast = take(h->convs.size() * sizeof(CastRange));
@@ -647,23 +651,23 @@ void assign_pointers(vk_unet* h) {
     if ((int)i == h->head_conv) continue;
     c.z = ws + h->off_z[i];
     c.g = h->cfg.training ? ws + h->off_g[i] : nullptr;
-    h->debug["z:" + c.name] = {c.z, {N, c.Hout, c.Hout, c.K}};
-    if (c.g) h->debug["g:" + c.name] = {c.g, {N, c.Hout, c.Hout, c.K}};
+    h->debug["z:" + c.name] = {c.z, {N, c.Hout, c.Wout, c.K}};
+    if (c.g) h->debug["g:" + c.name] = {c.g, {N, c.Hout, c.Wout, c.K}};
   }
   for (size_t b = 0; b < h->blocks.size(); ++b) {
     BlockL& k = h->blocks[b];
     k.out = ws + h->off_out[b];
     k.gout = h->cfg.training ? ws + h->off_gout[b] : nullptr;
     const std::string nm = h->convs[k.conv1].name.substr(0, h->convs[k.conv1].name.size() - 6);  // strip ".conv1"
-    h->debug["out:" + nm] = {k.out, {N, k.Hout, k.Hout, k.C}};
-    if (k.gout) h->debug["gout:" + nm] = {k.gout, {N, k.Hout, k.Hout, k.C}};
+    h->debug["out:" + nm] = {k.out, {N, k.Hout, k.Wout, k.C}};
+    if (k.gout) h->debug["gout:" + nm] = {k.gout, {N, k.Hout, k.Wout, k.C}};
   }
-  const int S = h->cfg.size;
-  h->debug["x4"] = {ws + h->off_x4, {N, S, S, 4}};
-  h->debug["pool"] = {ws + h->off_pool, {N, S / 4, S / 4, 64}};
+  const int S = h->cfg.size, SW = h->cfg.width;
+  h->debug["x4"] = {ws + h->off_x4, {N, S, SW, 4}};
+  h->debug["pool"] = {ws + h->off_pool, {N, S / 4, SW / 4, 64}};
   if (h->cfg.training) {
-    h->debug["gpool"] = {ws + h->off_gpool, {N, S / 4, S / 4, 64}};
-    h->debug["dlogits"] = {ws + h->off_dlogits, {N, S, S, 1}};
+    h->debug["gpool"] = {ws + h->off_gpool, {N, S / 4, SW / 4, 64}};
+    h->debug["dlogits"] = {ws + h->off_dlogits, {N, S, SW, 1}};
   }
   double* sp = (double*)(ws + h->off_stats);
   double* bp = (double*)(ws + h->off_bsums);
@@ -705,7 +709,7 @@ vk_src null_src() {
 vk_conv_desc conv_desc(const vk_unet* h, const ConvL& c, const vk_src& s0, const vk_src& s1) {
   vk_conv_desc d;
   d.dtype = h->cfg.dtype;
-  d.N = h->cfg.N; d.H = c.Hin; d.W = c.Hin; d.Ho = c.Hout; d.Wo = c.Hout;
+  d.N = h->cfg.N; d.H = c.Hin; d.W = c.Win; d.Ho = c.Hout; d.Wo = c.Wout;
   d.K = c.K; d.R = c.R; d.S = c.R; d.stride = c.stride; d.pad = c.pad; d.transposed = 0;
   d.src0 = s0; d.src1 = s1;
   return d;
@@ -773,11 +777,13 @@ extern "C" int vk_debug_hold_cus(int workgroups, int threads, int lds_bytes, int
 
 extern "C" int vk_unet_create(const vk_unet_config* cfg, vk_unet** out) {
   VK_CHECK_ARG(cfg && out, "vk_unet_create: null argument");
-  VK_CHECK_ARG(cfg->N >= 1 && cfg->size >= 32 && cfg->size % 32 == 0,
-               "Wrong input shape height=%d, width=%d: must be divisible by 32", cfg->size, cfg->size);
+  const int width = cfg->width > 0 ? cfg->width : cfg->size;
+  VK_CHECK_ARG(cfg->N >= 1 && cfg->size >= 32 && cfg->size % 32 == 0 && width >= 32 && width % 32 == 0,
+               "Wrong input shape height=%d, width=%d: must be divisible by 32", cfg->size, width);
   VK_CHECK_ARG(cfg->dtype == VK_F32 || cfg->dtype == VK_BF16 || cfg->dtype == VK_F16, "vk_unet_create: bad dtype");
   vk_unet* h = new vk_unet();
   h->cfg = *cfg;
+  h->cfg.width = width;
   h->eb = cfg->dtype == VK_F32 ? 4 : 2;
   build_topology(h);
   layout_workspace(h);
@@ -848,7 +854,7 @@ extern "C" int vk_unet_bind(vk_unet* h, float* params, float* grads, float* bn_b
       if (c.wd_off >= 0 && h->cfg.training) {
         vk_conv_desc d;
         d.dtype = h->cfg.dtype;
-        d.N = h->cfg.N; d.H = c.Hout; d.W = c.Hout; d.Ho = c.Hin; d.Wo = c.Hin;
+        d.N = h->cfg.N; d.H = c.Hout; d.W = c.Wout; d.Ho = c.Hin; d.Wo = c.Win;
         d.K = c.Cin; d.R = c.R; d.S = c.R; d.stride = c.stride; d.pad = c.pad; d.transposed = 1;
         d.src0 = plain(c.K);
         d.src1 = null_src();
@@ -965,7 +971,7 @@ extern "C" int vk_unet_forward(vk_unet* h, const float* x, float* logits, int tr
   VK_CHECK_ARG(h && h->bound && x && logits, "vk_unet_forward: plan not bound or null tensor");
   VK_CHECK_ARG(!training || h->cfg.training, "vk_unet_forward: training forward needs a training plan");
   hipStream_t st = (hipStream_t)stream;
-  const int N = h->cfg.N, S = h->cfg.size;
+  const int N = h->cfg.N, S = h->cfg.size, SW = h->cfg.width;
   const vk_dtype dt = h->cfg.dtype;
   if (training) {
     VK_CHECK_HIP(hipMemsetAsync(h->ws + h->off_stats, 0, h->stats_bytes, st));
@@ -976,13 +982,13 @@ extern "C" int vk_unet_forward(vk_unet* h, const float* x, float* logits, int tr
   }
   // stem
   void* x4 = h->ws + h->off_x4;
-  RET_IF(vk_input_transform(dt, N, S, S, x, x4, st));
+  RET_IF(vk_input_transform(dt, N, S, SW, x, x4, st));
   ConvL& stem = h->convs[h->stem_conv];
   BnL& sbn = h->bns[stem.bn];
-  RET_IF(vk_stem_fwd(dt, N, S, S, x4, h->ws + h->off_wstem, stem.z, training ? sbn.stats : nullptr, st));
+  RET_IF(vk_stem_fwd(dt, N, S, SW, x4, h->ws + h->off_wstem, stem.z, training ? sbn.stats : nullptr, st));
   RET_IF(finalize_bn(h, sbn, training, st));
   void* pool = h->ws + h->off_pool;
-  RET_IF(vk_bn_relu_maxpool(dt, N, S / 2, S / 2, 64, stem.z, sbn.scale, sbn.shift, pool, (uint8_t*)(h->ws + h->off_argmax), st));
+  RET_IF(vk_bn_relu_maxpool(dt, N, S / 2, SW / 2, 64, stem.z, sbn.scale, sbn.shift, pool, (uint8_t*)(h->ws + h->off_argmax), st));
   // encoder blocks
   Act cur{pool, 64, nullptr, nullptr, 0};
   for (BlockL& k : h->blocks) {
@@ -991,7 +997,7 @@ extern "C" int vk_unet_forward(vk_unet* h, const float* x, float* logits, int tr
     RET_IF(run_conv(h, c1, to_src(cur), null_src(), training, st));
     RET_IF(run_conv(h, c2, to_src(bn_act(h, c1)), null_src(), training, st));
     const BnL& b2 = h->bns[c2.bn];
-    const size_t pixels = (size_t)N * k.Hout * k.Hout;
+    const size_t pixels = (size_t)N * k.Hout * k.Wout;
     if (k.convd >= 0) {
       ConvL& cd = h->convs[k.convd];
       RET_IF(run_conv(h, cd, to_src(cur), null_src(), training, st));
@@ -1019,13 +1025,13 @@ extern "C" int vk_unet_forward(vk_unet* h, const float* x, float* logits, int tr
     // HBM).  Measured (profiles/r03/eval_tail_fusion.log): batch 1 0.691 -> 0.671 ms, but batch 16 1.690 -> 1.734 ms — the fused
     // tile's redundant halo work and three barriers cost more than the 33 MB per image they save against the streaming kernels — so
     // large plans keep the three launches.  VK_NO_TAIL_FUSION=1 / VK_TAIL_FUSION=1: never / always
-    const bool small_plan = (size_t)N * S * S <= 4u * 512 * 512;
+    const bool small_plan = (size_t)N * S * SW <= 4u * 512 * 512;
     if (!training && i + 1 == h->decs.size() && dt != VK_F32 && !d.Cskip && d.Cup == 32 && c1.K == 16 && c2.K == 16 && c1.halo_fwd &&
-        !c2.halo_fwd && S % 16 == 0 && !getenv("VK_NO_TAIL_FUSION") && (small_plan || getenv("VK_TAIL_FUSION"))) {
+        !c2.halo_fwd && S % 16 == 0 && SW % 16 == 0 && !getenv("VK_NO_TAIL_FUSION") && (small_plan || getenv("VK_TAIL_FUSION"))) {
       const vk_src s0 = to_src(xd, 1);
       const BnL& b1 = h->bns[c1.bn];
       const BnL& b2 = h->bns[c2.bn];
-      return vk_dec4_tail_eval(dt, N, S, S, &s0, fwd_weights(h, c1), b1.scale, b1.shift, fwd_weights(h, c2), b2.scale, b2.shift,
+      return vk_dec4_tail_eval(dt, N, S, SW, &s0, fwd_weights(h, c1), b1.scale, b1.shift, fwd_weights(h, c2), b2.scale, b2.shift,
                                h->params + h->head_w_off, h->params + h->head_b_off, logits, st);
     }
     RET_IF(run_conv(h, c1, to_src(xd, 1), d.Cskip ? to_src(skips[i]) : null_src(), training, st));
@@ -1034,7 +1040,7 @@ extern "C" int vk_unet_forward(vk_unet* h, const float* x, float* logits, int tr
   }
   // head
   vk_src hs = to_src(xd);
-  RET_IF(vk_head_fwd(dt, N, S, S, &hs, h->params + h->head_w_off, h->params + h->head_b_off, logits, st));
+  RET_IF(vk_head_fwd(dt, N, S, SW, &hs, h->params + h->head_w_off, h->params + h->head_b_off, logits, st));
   if (training) {
     hipLaunchKernelGGL(k_inc_i64, dim3(1), dim3(64), 0, st, (int)h->bns.size(), h->nbt);
     VK_CHECK_HIP(hipGetLastError());
@@ -1045,7 +1051,7 @@ extern "C" int vk_unet_forward(vk_unet* h, const float* x, float* logits, int tr
 extern "C" int vk_unet_loss(vk_unet* h, const float* logits, const float* target, float* loss_out, float grad_scale, float w_bce,
                             float w_dice, void* stream) {
   VK_CHECK_ARG(h && h->bound && logits && target && loss_out, "vk_unet_loss: plan not bound or null tensor");
-  const size_t count = (size_t)h->cfg.N * h->cfg.size * h->cfg.size;
+  const size_t count = (size_t)h->cfg.N * h->cfg.size * h->cfg.width;
   float* dl = h->cfg.training ? (float*)(h->ws + h->off_dlogits) : nullptr;
   return vk_bce_dice_loss(count, logits, target, (double*)(h->ws + h->off_loss_sums), loss_out, dl, grad_scale, w_bce, w_dice, stream);
 }
@@ -1057,7 +1063,7 @@ namespace {
 // prereduced: the producer of c.g already stored g = dy * mask and accumulated the sums (vk_bnr fusion)
 int bn_relu_bwd_inplace(vk_unet* h, ConvL& c, bool prereduced, hipStream_t st) {
   BnL& b = h->bns[c.bn];
-  const size_t pixels = (size_t)h->cfg.N * c.Hout * c.Hout;
+  const size_t pixels = (size_t)h->cfg.N * c.Hout * c.Wout;
   if (!prereduced) RET_IF(vk_bn_bwd_reduce(h->cfg.dtype, pixels, c.K, c.g, c.z, 1, b.scale, b.shift, nullptr, b.bsums, st));
   RET_IF(vk_bn_bwd_coeffs(c.K, b.bsums, b.count, h->params + b.g_off, b.mean, b.invstd, h->grads + b.g_off, h->grads + b.b_off, b.coef, st));
   return vk_bn_bwd_apply(h->cfg.dtype, pixels, c.K, c.g, c.z, prereduced ? 0 : 1, b.scale, b.shift, nullptr, b.coef, c.g, nullptr, 0, st);
@@ -1106,7 +1112,7 @@ vk_bnr bnr_of(vk_unet* h, ConvL& target) {     // fused BN+ReLU backward reduce 
 vk_conv_desc dgrad_desc(vk_unet* h, ConvL& c) {
   vk_conv_desc d;
   d.dtype = h->cfg.dtype;
-  d.N = h->cfg.N; d.H = c.Hout; d.W = c.Hout; d.Ho = c.Hin; d.Wo = c.Hin;
+  d.N = h->cfg.N; d.H = c.Hout; d.W = c.Wout; d.Ho = c.Hin; d.Wo = c.Win;
   d.K = c.Cin; d.R = c.R; d.S = c.R; d.stride = c.stride; d.pad = c.pad; d.transposed = 1;
   vk_src s;
   s.ptr = c.g; s.C = c.K; s.up = 0; s.scale = nullptr; s.shift = nullptr; s.relu = 0;
@@ -1131,7 +1137,7 @@ int conv_dgrad_into(vk_unet* h, ConvL& c, ConvL& into, bool* fused, hipStream_t 
 int conv_dgrad(vk_unet* h, ConvL& c, void* y, void* y1, int split, int accumulate, hipStream_t st) {
   vk_conv_desc d;
   d.dtype = h->cfg.dtype;
-  d.N = h->cfg.N; d.H = c.Hout; d.W = c.Hout; d.Ho = c.Hin; d.Wo = c.Hin;
+  d.N = h->cfg.N; d.H = c.Hout; d.W = c.Wout; d.Ho = c.Hin; d.Wo = c.Win;
   d.K = c.Cin; d.R = c.R; d.S = c.R; d.stride = c.stride; d.pad = c.pad; d.transposed = 1;
   vk_src s;
   s.ptr = c.g; s.C = c.K; s.up = 0; s.scale = nullptr; s.shift = nullptr; s.relu = 0;
@@ -1195,7 +1201,7 @@ int backward_decoder(vk_unet* h, int i, hipStream_t st) {
       void* dup = h->ws + h->off_dup;
       if (d.Cskip) RET_IF(conv_dgrad(h, c1, dup, g_skip, d.Cup, 0, st));
       else RET_IF(conv_dgrad(h, c1, dup, nullptr, 0, 0, st));
-      RET_IF(vk_upsample2x_bwd(h->cfg.dtype, N, d.H, d.H, d.Cup, dup, g_prev, 0, st));
+      RET_IF(vk_upsample2x_bwd(h->cfg.dtype, N, d.H, d.W, d.Cup, dup, g_prev, 0, st));
     }
   }
   return conv_wgrad(h, c1, to_src(xprev, 1), d.Cskip ? to_src(skip) : null_src(), st);
@@ -1207,7 +1213,7 @@ int backward_block(vk_unet* h, int bi, hipStream_t st) {
   ConvL& c2 = h->convs[k.conv2];
   BnL& b2 = h->bns[c2.bn];
   const vk_dtype dt = h->cfg.dtype;
-  const size_t pixels = (size_t)h->cfg.N * k.Hout * k.Hout;
+  const size_t pixels = (size_t)h->cfg.N * k.Hout * k.Wout;
   // block input (materialised) and its gradient buffer
   Act xin;
   void* gin;
@@ -1272,22 +1278,22 @@ int backward_block(vk_unet* h, int bi, hipStream_t st) {
 }
 
 int backward_stem(vk_unet* h, hipStream_t st) {
-  const int N = h->cfg.N, S = h->cfg.size;
+  const int N = h->cfg.N, S = h->cfg.size, SW = h->cfg.width;
   ConvL& stem = h->convs[h->stem_conv];
   // stem.g holds the skip gradient of f1 (from decoder block 3); add the maxpool path
   if (getenv("VK_NO_POOL_BNR_FUSION")) {
-    RET_IF(vk_maxpool_bwd(h->cfg.dtype, N, S / 2, S / 2, 64, h->ws + h->off_gpool, (const uint8_t*)(h->ws + h->off_argmax), stem.g, st));
+    RET_IF(vk_maxpool_bwd(h->cfg.dtype, N, S / 2, SW / 2, 64, h->ws + h->off_gpool, (const uint8_t*)(h->ws + h->off_argmax), stem.g, st));
     RET_IF(bn_relu_bwd_inplace(h, stem, false, st));
   } else {
     // one pass: maxpool backward + mask + BN-backward sums (saves a read-modify-write and a read of the 256x256x64 gradient)
     BnL& b = h->bns[stem.bn];
-    RET_IF(vk_maxpool_bwd_bn_reduce(h->cfg.dtype, N, S / 2, S / 2, 64, h->ws + h->off_gpool, (const uint8_t*)(h->ws + h->off_argmax), stem.z,
+    RET_IF(vk_maxpool_bwd_bn_reduce(h->cfg.dtype, N, S / 2, SW / 2, 64, h->ws + h->off_gpool, (const uint8_t*)(h->ws + h->off_argmax), stem.z,
                                     b.scale, b.shift, stem.g, b.bsums, st));
     RET_IF(bn_relu_bwd_inplace(h, stem, true, st));
   }
   hipStream_t ws;
   RET_IF(wgrad_stream(h, st, &ws));
-  return vk_stem_wgrad(h->cfg.dtype, N, S, S, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, ws);
+  return vk_stem_wgrad(h->cfg.dtype, N, S, SW, h->ws + h->off_x4, stem.g, h->grads + stem.w_off, h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, ws);
 }
 
 // the collected weight gradients of a stage: one batched launch (tables built once per stage and per workgroup budget), a single one
@@ -1328,7 +1334,7 @@ int flush_wgrads(vk_unet* h, int stage, hipStream_t st) {
 }
 
 int backward_stage(vk_unet* h, const float* dlogits, int stage, hipStream_t st) {
-  const int N = h->cfg.N, S = h->cfg.size;
+  const int N = h->cfg.N, S = h->cfg.size, SW = h->cfg.width;
   switch (stage) {
     case 0: {
       VK_CHECK_HIP(hipMemsetAsync(h->ws + h->off_bsums, 0, h->stats_bytes, st));
@@ -1338,9 +1344,9 @@ int backward_stage(vk_unet* h, const float* dlogits, int stage, hipStream_t st) 
         vk_bnr r = bnr_of(h, last);
         const bool fuse = !getenv("VK_NO_BNR_FUSION");
         const float* dl = dlogits ? dlogits : (const float*)(h->ws + h->off_dlogits);
-        if (fuse) RET_IF(vk_head_bwd_fused(h->cfg.dtype, N, S, S, &hs, h->params + h->head_w_off, dl, last.g, h->grads + h->head_w_off,
+        if (fuse) RET_IF(vk_head_bwd_fused(h->cfg.dtype, N, S, SW, &hs, h->params + h->head_w_off, dl, last.g, h->grads + h->head_w_off,
                                            h->grads + h->head_b_off, &r, h->ws + h->off_wslab, VK_HEAD_WORKSPACE_BYTES, st));
-        else RET_IF(vk_head_bwd(h->cfg.dtype, N, S, S, &hs, h->params + h->head_w_off, dl, last.g, h->grads + h->head_w_off,
+        else RET_IF(vk_head_bwd(h->cfg.dtype, N, S, SW, &hs, h->params + h->head_w_off, dl, last.g, h->grads + h->head_w_off,
                                 h->grads + h->head_b_off, h->ws + h->off_wslab, VK_HEAD_WORKSPACE_BYTES, st));
         h->g_prereduced[h->decs[4].conv2] = fuse ? 1 : 0;
       }

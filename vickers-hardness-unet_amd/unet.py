@@ -36,11 +36,12 @@ class _Plan:
     """One engine handle + workspace for a fixed (N, size, dtype, training) — static shapes, static
     addresses (hipGraph-friendly)."""
 
-    def __init__(self, model: "Unet", N: int, S: int, dtype: torch.dtype, training: bool):
+    def __init__(self, model: "Unet", N: int, S, dtype: torch.dtype, training: bool):
         L = lib()
+        H, W = (S, S) if isinstance(S, int) else S          # S: the side of a square input or (height, width)
         self.key = (N, S, dtype, training)
-        self.N, self.S, self.dtype, self.training = N, S, dtype, training
-        cfg = _lib.vk_unet_config(N, S, _lib.dtype_code(dtype), 1 if training else 0)
+        self.N, self.S, self.H, self.W, self.dtype, self.training = N, S, H, W, dtype, training
+        cfg = _lib.vk_unet_config(N, H, _lib.dtype_code(dtype), 1 if training else 0, W)
         h = C.c_void_p()
         check(L.vk_unet_create(C.byref(cfg), C.byref(h)), "vk_unet_create")
         self.h = h
@@ -290,7 +291,7 @@ class Unet(nn.Module):
         return (self._dirty, sum(p._version for p in self._param_list))
 
     # ------------------------------------------------------------------ plans
-    def plan_for(self, N: int, S: int, dtype: torch.dtype, training: bool) -> _Plan:
+    def plan_for(self, N: int, S, dtype: torch.dtype, training: bool) -> _Plan:
         key = (N, S, dtype, training)
         p = self._plans.get(key)
         if p is None and not training:
@@ -306,8 +307,6 @@ class Unet(nn.Module):
         h, w = x.shape[-2:]
         if h % 32 or w % 32:
             raise RuntimeError(f"Wrong input shape height={h}, width={w}. Expected image height and width divisible by 32.")
-        if h != w:
-            raise NotImplementedError("square inputs only (the reference letterboxes every image to img_size x img_size)")
         if not x.is_cuda:
             raise VkError("input is on %s: this package runs on an MI355X only and has no CPU fallback" % x.device)
         if self._flat["params"].device != x.device:
@@ -321,7 +320,7 @@ class Unet(nn.Module):
             check(L.vk_unet_refresh_weights(plan.h, st), "vk_unet_refresh_weights")
             plan.weights_version = ver
         x = x.detach().contiguous().float()
-        logits = torch.empty(plan.N, 1, plan.S, plan.S, dtype=torch.float32, device=x.device)
+        logits = torch.empty(plan.N, 1, plan.H, plan.W, dtype=torch.float32, device=x.device)
         check(L.vk_unet_forward(plan.h, x.data_ptr(), logits.data_ptr(), 1 if training else 0, st), "vk_unet_forward")
         plan._last_x = x      # keep the input alive until backward has consumed the plan's x4 copy
         return logits
@@ -386,7 +385,8 @@ class Unet(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_input(x)
-        N, _, S, _ = x.shape
+        N, _, H, W = x.shape
+        S = H if H == W else (H, W)           # plans are keyed by the side of a square input or by (height, width)
         if torch.is_autocast_enabled():
             dtype = torch.get_autocast_dtype('cuda')
         else:
@@ -404,8 +404,8 @@ class Unet(nn.Module):
         head gradient directly.  Returns a device tensor [total, bce, dice] (no host sync).
         Equivalent to train.py:436-448 ``logits = model(x); loss = bce + dice; loss.backward()``."""
         self._check_input(x)
-        N, _, S, _ = x.shape
-        plan = self.plan_for(N, S, dtype or self.compute_dtype, True)
+        N, _, H, W = x.shape
+        plan = self.plan_for(N, H if H == W else (H, W), dtype or self.compute_dtype, True)
         logits = self._run_forward(plan, x, True)
         y = y.detach().contiguous().float()
         check(lib().vk_unet_loss(plan.h, logits.data_ptr(), y.data_ptr(), plan.loss_out.data_ptr(), float(grad_scale),
