@@ -239,3 +239,6 @@ def test_shipped_binary_has_no_uncovered_mfma_hazard(vk):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     m = re.search(r"(\d+) kernels with MFMAs: 0 violation", tail)
     assert m and int(m.group(1)) >= 100, tail
+    # no kernel of the compute path spills or uses scratch (the geometry post-processing kernels keep small per-thread arrays there by design)
+    scratch = [l for l in r.stdout.splitlines() if l.startswith("scratch: ")]
+    assert all(l.split()[1].startswith("_ZN2vk11k_geom_") or l.split()[1].startswith("_ZN2vk12k_geom_") for l in scratch), scratch

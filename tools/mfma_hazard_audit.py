@@ -177,6 +177,23 @@ def audit(path):
     return bad, info
 
 
+def scratch_report(co_files):
+    """[(kernel, scratch bytes, vgprs, spilled vgprs)] for every kernel of the code objects that uses scratch memory or spills
+    (llvm-readelf --notes: the AMDGPU metadata).  r04: an edit that pushed a 250-register tile kernel over its cap spilled 11
+    registers into the epilogue without any diagnostic — the CPU suite now looks."""
+    import os
+    import subprocess
+    llvm = os.environ.get("VK_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+    out = []
+    pat = re.compile(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)")
+    for co in co_files:
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+        for m in pat.finditer(notes):
+            if int(m.group(2)) or int(m.group(4)):
+                out.append((m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))))
+    return out
+
+
 def main():
     args = sys.argv[1:]
     if not args:
@@ -203,6 +220,12 @@ def main():
                   + (f"\n  via taken branches: {trail}" if trail else ""))
         for x in sorted(set(info)):
             print("info:", x)
+    for f in files:
+        co = f[:-4] + ".co"
+        import os
+        if f.endswith(".dis") and os.path.exists(co):
+            for name, scratch, vgprs, spills in scratch_report([co]):
+                print(f"scratch: {name} private_segment {scratch} B, {vgprs} VGPRs, {spills} spilled")
     print(f"{len(files)} file(s), {nk} kernels with MFMAs: {total} violation(s)")
     if tmp:
         import shutil

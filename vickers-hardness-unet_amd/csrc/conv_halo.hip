@@ -129,22 +129,6 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
   static_assert(BM % ERPP == 0 && EVPR <= 64, "epilogue mapping");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
-#pragma unroll
-  for (int a = 0; a < TC; ++a)
-#pragma unroll
-    for (int b = 0; b < TP; ++b) {
-      const int ch = wch0 + a * 16 + kg * 4;
-      const int px = (wrow0 + b) * 16 + li;
-      char* dst = smem + px * ESB + ch * EB;
-      if (EB == 4) {
-        *reinterpret_cast<f32x4_t*>(dst) = acc[a][b];
-      } else {
-        float f[8] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3], 0.f, 0.f, 0.f, 0.f};
-        const u32x4_t pk = Vec16<T>::pack(f);
-        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pk[0], pk[1]};
-      }
-    }
-  __syncthreads();
 
   // thread -> (tile pixel, 16-byte vector of its channel row).  BN = 128, 16-bit (rows of 272 bytes, 16 vectors): the odd rows take
   // their vectors rotated by one — the 16-lane groups of a ds_read_b128 then see 16 different 16-byte slots of the 256-byte bank row
@@ -207,6 +191,53 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
     }
     *gp = v;
   };
+  // r04: these requests are issued BEFORE the accumulators go through LDS (they depend on nothing the tile computed): the HBM round
+  // trip of up to 3 x EPASS vectors per thread runs under the transposition and its barrier instead of behind them
+  // PRE: request the accumulate / bnr operands of all EPASS vectors before the first one is finished (one memory round
+  // trip instead of EPASS; pays on the 64-channel tiles with 8 passes per thread: L1 data gradient + reduce 73 -> 70 us,
+  // costs registers, hence occupancy, on the C = 16 kernels: off there)
+  constexpr bool PRE_M = PRE && NT == 512;       // the external-mask vectors ride along only where registers allow (4-wave 64-channel tile: 250 of 256 in use)
+  u32x4_t oldv[PRE ? EPASS : 1], zv[PRE ? EPASS : 1], mv[PRE_M ? EPASS : 1];
+  // early only on the 8-wave tiles (256 registers per wave): beside the live accumulators the 3 x EPASS vectors would cost the 4-wave
+  // tiles their second workgroup per CU
+  constexpr bool EARLY = PRE && NT == 512;
+  auto request_pre = [&]() {
+    if (!(PRE && (p.accumulate || bnr) && !(p.pool2 && first_part))) return;
+#pragma unroll
+    for (int ps = 0; ps < (PRE ? EPASS : 0); ++ps) {
+      const int row = e_row + ps * ERPP;
+      const int y = OS * (y0 + (row >> 4)) + py, x = OS * (x0 + (row & 15)) + px;
+      oldv[ps] = u32x4_t{0, 0, 0, 0};
+      zv[ps] = u32x4_t{0, 0, 0, 0};
+      if (PRE_M) mv[ps] = u32x4_t{0, 0, 0, 0};
+      if (y < p.H && x < p.W && col_ok) {
+        const size_t eoff = (((size_t)n * p.H + y) * p.W + x) * ld + colx;
+        if (p.accumulate) oldv[ps] = *reinterpret_cast<const u32x4_t*>(yb + eoff * EB);
+        if (bnr) zv[ps] = *reinterpret_cast<const u32x4_t*>((const char*)p.bnr_z + eoff * EB);
+        if (PRE_M && bnr && ext_mask) mv[ps] = *reinterpret_cast<const u32x4_t*>((const char*)p.bnr_mask + eoff * EB);
+      }
+    }
+  };
+  if (EARLY) request_pre();
+  // ---- accumulators -> LDS [tile pixel][channel] as T
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+      const int ch = wch0 + a * 16 + kg * 4;
+      const int px = (wrow0 + b) * 16 + li;
+      char* dst = smem + px * ESB + ch * EB;
+      if (EB == 4) {
+        *reinterpret_cast<f32x4_t*>(dst) = acc[a][b];
+      } else {
+        float f[8] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3], 0.f, 0.f, 0.f, 0.f};
+        const u32x4_t pk = Vec16<T>::pack(f);
+        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pk[0], pk[1]};
+      }
+    }
+  __syncthreads();
+  if (!EARLY) request_pre();
+
   if (p.pool2 && first_part) {
     // (TH/2) x 8 pooled pixels; tile origins are even, H and W are even
     const int Hh = p.H >> 1, Wh = p.W >> 1;
@@ -229,26 +260,6 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
       }
     }
   } else {
-    // PRE: request the accumulate / bnr operands of all EPASS vectors before the first one is finished (one memory round
-    // trip instead of EPASS; pays on the 64-channel tiles with 8 passes per thread: L1 data gradient + reduce 73 -> 70 us,
-    // costs registers, hence occupancy, on the C = 16 kernels: off there)
-    u32x4_t oldv[PRE ? EPASS : 1], zv[PRE ? EPASS : 1], mv[PRE ? EPASS : 1];
-    if (PRE && (p.accumulate || bnr)) {
-#pragma unroll
-      for (int ps = 0; ps < (PRE ? EPASS : 0); ++ps) {
-        const int row = e_row + ps * ERPP;
-        const int y = OS * (y0 + (row >> 4)) + py, x = OS * (x0 + (row & 15)) + px;
-        oldv[ps] = u32x4_t{0, 0, 0, 0};
-        zv[ps] = u32x4_t{0, 0, 0, 0};
-        mv[ps] = u32x4_t{0, 0, 0, 0};
-        if (y < p.H && x < p.W && col_ok) {
-          const size_t eoff = (((size_t)n * p.H + y) * p.W + x) * ld + colx;
-          if (p.accumulate) oldv[ps] = *reinterpret_cast<const u32x4_t*>(yb + eoff * EB);
-          if (bnr) zv[ps] = *reinterpret_cast<const u32x4_t*>((const char*)p.bnr_z + eoff * EB);
-          if (bnr && ext_mask) mv[ps] = *reinterpret_cast<const u32x4_t*>((const char*)p.bnr_mask + eoff * EB);
-        }
-      }
-    }
 #pragma unroll
     for (int ps = 0; ps < EPASS; ++ps) {
       const int row = e_row + ps * ERPP;          // tile pixel index
@@ -259,7 +270,7 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
         float f[VE];
         if (p.accumulate || bnr) {
           Vec16<T>::unpack(raw, f);
-          if (PRE) finish(f, eoff, &oldv[ps], &zv[ps], &mv[ps]);
+          if (PRE) finish(f, eoff, &oldv[ps], &zv[ps], PRE_M ? &mv[ps] : nullptr);
           else finish(f, eoff, nullptr, nullptr);
         } else {
           // plain store: the LDS tile already holds the rounded values, so they go out as they are (no pack / unpack round
@@ -1252,7 +1263,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_colq_kernel(const H
       }
     return;
   }
-  halo_epilogue<T, TH, BN, TP, TC, NT, (VK_COLQ_PRE || (BN <= 64 && TH == 16))>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
+  halo_epilogue<T, TH, BN, TP, TC, NT, ((VK_COLQ_PRE && sizeof(T) == 2) || (BN <= 64 && TH == 16))>(smem, acc, p, n, y0, x0, n0, wrow0, wch0);
 }
 
 // ---- staggered form of the pipelined kernel (r03): the same tile, operand order and epilogue (bit-identical results), but the two
