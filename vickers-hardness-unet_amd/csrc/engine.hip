@@ -1257,7 +1257,8 @@ int backward_block(vk_unet* h, int bi, hipStream_t st) {
   // separate reduce pass (3 tensor reads) and the mask reads of the apply passes go (train.py:443/:448: autograd's relu / add /
   // batch_norm backward nodes of torchvision's BasicBlock).  Downsample blocks finish gin with their 1x1 data gradient: not fused.
   bool tail_fused = false;
-  if (k.convd < 0 && bi > 0 && c1.halo_dg && !getenv("VK_NO_TAIL_BNR_FUSION")) {
+  const int tail_maxc = getenv("VK_TAIL_BNR_MAXC") ? atoi(getenv("VK_TAIL_BNR_MAXC")) : 1 << 20;      // experiment knob: fuse only up to this width
+  if (k.convd < 0 && bi > 0 && c1.halo_dg && k.C <= tail_maxc && !getenv("VK_NO_TAIL_BNR_FUSION")) {
     BlockL& pb = h->blocks[bi - 1];
     ConvL& pc2 = h->convs[pb.conv2];
     vk_conv_desc dd = dgrad_desc(h, c1);
