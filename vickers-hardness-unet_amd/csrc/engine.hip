@@ -1057,7 +1057,24 @@ extern "C" int vk_unet_loss(vk_unet* h, const float* logits, const float* target
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+#ifndef VK_BN_APPLY_FUSED_MAXC_DEFAULT
+#define VK_BN_APPLY_FUSED_MAXC_DEFAULT 0
+#endif
 namespace {
+
+// BatchNorm backward, phase 2: coefficients (a, b, c) + dgamma / dbeta from the reduction sums, then dz = a*g + b*z + c.  Two launches
+// (k_bn_bwd_coeffs: 8 channels per workgroup, fp64; then the sweep reads 3 C floats) or ONE (vk_bn_bwd_apply_fused: every workgroup of
+// the sweep adds the 32 replicas of all C channels itself — 512 C bytes from L2 per workgroup): the second form takes a launch-bound
+// ~6 us kernel off the critical path where C is small and the tensor large (VK_BN_APPLY_FUSED_MAXC, measured in profiles/r04/).
+int bn_bwd_phase2(vk_unet* h, BnL& b, int C, size_t pixels, const void* dy, const void* z, int mask_mode, const void* mask_src, void* dz,
+                  void* g_out, int g_acc, hipStream_t st) {
+  static const int maxc = getenv("VK_BN_APPLY_FUSED_MAXC") ? atoi(getenv("VK_BN_APPLY_FUSED_MAXC")) : VK_BN_APPLY_FUSED_MAXC_DEFAULT;
+  if (C <= maxc)
+    return vk_bn_bwd_apply_fused(h->cfg.dtype, pixels, C, dy, z, mask_mode, b.scale, b.shift, mask_src, b.bsums, b.count, h->params + b.g_off,
+                                 b.mean, b.invstd, h->grads + b.g_off, h->grads + b.b_off, dz, g_out, g_acc, st);
+  RET_IF(vk_bn_bwd_coeffs(C, b.bsums, b.count, h->params + b.g_off, b.mean, b.invstd, h->grads + b.g_off, h->grads + b.b_off, b.coef, st));
+  return vk_bn_bwd_apply(h->cfg.dtype, pixels, C, dy, z, mask_mode, b.scale, b.shift, mask_src, b.coef, dz, g_out, g_acc, st);
+}
 
 // gradient wrt activated output (in c.g) -> gradient wrt z (in place); dgamma/dbeta accumulated
 // prereduced: the producer of c.g already stored g = dy * mask and accumulated the sums (vk_bnr fusion)
@@ -1065,8 +1082,7 @@ int bn_relu_bwd_inplace(vk_unet* h, ConvL& c, bool prereduced, hipStream_t st) {
   BnL& b = h->bns[c.bn];
   const size_t pixels = (size_t)h->cfg.N * c.Hout * c.Wout;
   if (!prereduced) RET_IF(vk_bn_bwd_reduce(h->cfg.dtype, pixels, c.K, c.g, c.z, 1, b.scale, b.shift, nullptr, b.bsums, st));
-  RET_IF(vk_bn_bwd_coeffs(c.K, b.bsums, b.count, h->params + b.g_off, b.mean, b.invstd, h->grads + b.g_off, h->grads + b.b_off, b.coef, st));
-  return vk_bn_bwd_apply(h->cfg.dtype, pixels, c.K, c.g, c.z, prereduced ? 0 : 1, b.scale, b.shift, nullptr, b.coef, c.g, nullptr, 0, st);
+  return bn_bwd_phase2(h, b, c.K, pixels, c.g, c.z, prereduced ? 0 : 1, nullptr, c.g, nullptr, 0, st);
 }
 
 // stream the weight-gradient kernels run on: the side stream, forked here behind everything enqueued on `st` so far
@@ -1234,16 +1250,13 @@ int backward_block(vk_unet* h, int bi, hipStream_t st) {
   if (!pre) RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, c2.z, 2, nullptr, nullptr, k.out, b2.bsums, st));
   if (k.convd < 0) {
     // identity shortcut: gin (+)= g
-    RET_IF(vk_bn_bwd_coeffs(k.C, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd, h->grads + b2.g_off, h->grads + b2.b_off, b2.coef, st));
-    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, mm, nullptr, nullptr, k.out, b2.coef, c2.g, gin, k.in_has_grad_first ? 1 : 0, st));
+    RET_IF(bn_bwd_phase2(h, b2, k.C, pixels, k.gout, c2.z, mm, k.out, c2.g, gin, k.in_has_grad_first ? 1 : 0, st));
   } else {
     ConvL& cd = h->convs[k.convd];
     BnL& bd = h->bns[cd.bn];
-    RET_IF(vk_bn_bwd_coeffs(k.C, b2.bsums, b2.count, h->params + b2.g_off, b2.mean, b2.invstd, h->grads + b2.g_off, h->grads + b2.b_off, b2.coef, st));
-    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, c2.z, mm, nullptr, nullptr, k.out, b2.coef, c2.g, nullptr, 0, st));
+    RET_IF(bn_bwd_phase2(h, b2, k.C, pixels, k.gout, c2.z, mm, k.out, c2.g, nullptr, 0, st));
     RET_IF(vk_bn_bwd_reduce(dt, pixels, k.C, k.gout, cd.z, mm, nullptr, nullptr, k.out, bd.bsums, st));
-    RET_IF(vk_bn_bwd_coeffs(k.C, bd.bsums, bd.count, h->params + bd.g_off, bd.mean, bd.invstd, h->grads + bd.g_off, h->grads + bd.b_off, bd.coef, st));
-    RET_IF(vk_bn_bwd_apply(dt, pixels, k.C, k.gout, cd.z, mm, nullptr, nullptr, k.out, bd.coef, cd.g, nullptr, 0, st));
+    RET_IF(bn_bwd_phase2(h, bd, k.C, pixels, k.gout, cd.z, mm, k.out, cd.g, nullptr, 0, st));
   }
   // conv2 (data gradient first, weight gradient after it: see backward_decoder)
   bool fused1 = false;
