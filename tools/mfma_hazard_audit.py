@@ -178,19 +178,20 @@ def audit(path):
 
 
 def scratch_report(co_files):
-    """[(kernel, scratch bytes, vgprs, spilled vgprs)] for every kernel of the code objects that uses scratch memory or spills
+    """[(kernel, scratch bytes, vgprs, spilled vgprs, spilled sgprs)] for every kernel of the code objects that uses scratch memory or spills
     (llvm-readelf --notes: the AMDGPU metadata).  r04: an edit that pushed a 250-register tile kernel over its cap spilled 11
     registers into the epilogue without any diagnostic — the CPU suite now looks."""
     import os
     import subprocess
     llvm = os.environ.get("VK_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
     out = []
-    pat = re.compile(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)")
+    pat = re.compile(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)\n(?:.*\n)*?"
+                     r"\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)")
     for co in co_files:
         notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
         for m in pat.finditer(notes):
-            if int(m.group(2)) or int(m.group(4)):
-                out.append((m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))))
+            if int(m.group(2)) or int(m.group(5)):
+                out.append((m.group(1), int(m.group(2)), int(m.group(4)), int(m.group(5)), int(m.group(3))))
     return out
 
 
@@ -224,8 +225,13 @@ def main():
         co = f[:-4] + ".co"
         import os
         if f.endswith(".dis") and os.path.exists(co):
-            for name, scratch, vgprs, spills in scratch_report([co]):
-                print(f"scratch: {name} private_segment {scratch} B, {vgprs} VGPRs, {spills} spilled")
+            for name, scratch, vgprs, spills, sspills in scratch_report([co]):
+                # scalar registers parked in VGPR lanes (v_writelane / v_readlane) leave their frame slots in the private-segment size
+                # although no instruction touches scratch memory: reported apart from real scratch use
+                if spills == 0 and sspills > 0 and scratch <= 4 * sspills:
+                    print(f"sgpr-spill: {name} {sspills} SGPRs in VGPR lanes (private_segment {scratch} B unused), {vgprs} VGPRs")
+                else:
+                    print(f"scratch: {name} private_segment {scratch} B, {vgprs} VGPRs, {spills} spilled")
     print(f"{len(files)} file(s), {nk} kernels with MFMAs: {total} violation(s)")
     if tmp:
         import shutil

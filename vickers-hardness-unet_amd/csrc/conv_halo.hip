@@ -38,6 +38,12 @@ struct HaloSrc {
 };
 
 // -DVK_COLQ_PRE=0: the pipelined K >= 128 kernel's epilogue requests the accumulate / BN-backward operands pass by pass (r03 form)
+#ifndef VK_EPI_BATCH_READS
+#define VK_EPI_BATCH_READS 1    // plain-store epilogue: the tile rows of up to 8 passes are read from LDS up front (0: one read -> wait -> store per pass, r03)
+#endif
+#ifndef VK_COLP_DEFER_STATS
+#define VK_COLP_DEFER_STATS 1   // persistent K < 128 kernel: BN sums accumulate across a workgroup's tiles, one atomic pair at the end (0: per tile, r03)
+#endif
 #ifndef VK_COLQ_PRE
 #define VK_COLQ_PRE 1
 #endif
@@ -119,7 +125,7 @@ __device__ __forceinline__ int halo_group(int tid) {
 //   * OS = 2 (stride-2 data gradient): tile pixel (row, col) is output pixel (2 (y0 + row) + py, 2 (x0 + col) + px)
 template <typename T, int TH, int BN, int TP, int TC, int NT = 256, bool PRE = false, int OS = 1>
 __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP], const HaloParams& p, int n, int y0, int x0, int n0,
-                                              int wrow0, int wch0, int py = 0, int px = 0) {
+                                              int wrow0, int wch0, int py = 0, int px = 0, double* defer = nullptr) {
   using Tr = ElemTraits<T>;
   constexpr int EB = Tr::kBytes, VE = Tr::kVec;
   constexpr int BM = TH * 16;
@@ -259,7 +265,7 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
         finish(f, (((size_t)n * Hh + y) * Wh + x) * ld + colx, nullptr, nullptr);
       }
     }
-  } else {
+  } else if (p.accumulate || p.bnr_z != nullptr) {          // (launch-uniform)
 #pragma unroll
     for (int ps = 0; ps < EPASS; ++ps) {
       const int row = e_row + ps * ERPP;          // tile pixel index
@@ -268,20 +274,38 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
         const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(smem + row * ESB + e_vec * 16);
         const size_t eoff = (((size_t)n * p.H + y) * p.W + x) * ld + colx;
         float f[VE];
-        if (p.accumulate || bnr) {
-          Vec16<T>::unpack(raw, f);
-          if (PRE) finish(f, eoff, &oldv[ps], &zv[ps], PRE_M ? &mv[ps] : nullptr);
-          else finish(f, eoff, nullptr, nullptr);
-        } else {
-          // plain store: the LDS tile already holds the rounded values, so they go out as they are (no pack / unpack round
-          // trip) and only a launch that wants BN statistics pays for the sums
-          if (p.stats) {
-            Vec16<T>::unpack(raw, f);
+        Vec16<T>::unpack(raw, f);
+        if (PRE) finish(f, eoff, &oldv[ps], &zv[ps], PRE_M ? &mv[ps] : nullptr);
+        else finish(f, eoff, nullptr, nullptr);
+      }
+    }
+  } else {
+    // plain store: the LDS tile already holds the rounded values, so they go out as they are (no pack / unpack round trip) and only
+    // a launch that wants BN statistics pays for the sums.  r04: the tile rows of up to 8 passes are read from LDS up front (in
+    // bounds for every thread) instead of one dependent ds_read -> wait -> store chain per pass behind the bounds branch
+    // (VK_EPI_BATCH_READS=0: the r03 order); the operand vectors of the path above are dead here, so this costs no registers.
+    // Measured null on layers 1-2 (profiles/r04/epi_batch_ab.log): the other workgroup of the CU hides the chain
+    constexpr int RB = VK_EPI_BATCH_READS ? (EPASS < 8 ? EPASS : 8) : 1;
+    u32x4_t raws[RB];
 #pragma unroll
-            for (int j = 0; j < VE; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
-          }
-          *reinterpret_cast<u32x4_t*>(yb + eoff * EB) = raw;
+    for (int ps = 0; ps < EPASS; ++ps) {
+      if (ps % RB == 0) {
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+          if (ps + q < EPASS) raws[q] = *reinterpret_cast<const u32x4_t*>(smem + (e_row + (ps + q) * ERPP) * ESB + e_vec * 16);
+      }
+      const int row = e_row + ps * ERPP;
+      const int y = OS * (y0 + (row >> 4)) + py, x = OS * (x0 + (row & 15)) + px;
+      if (y < p.H && x < p.W && col_ok) {
+        const u32x4_t raw = raws[ps % RB];
+        const size_t eoff = (((size_t)n * p.H + y) * p.W + x) * ld + colx;
+        if (p.stats) {
+          float f[VE];
+          Vec16<T>::unpack(raw, f);
+#pragma unroll
+          for (int j = 0; j < VE; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
         }
+        *reinterpret_cast<u32x4_t*>(yb + eoff * EB) = raw;
       }
     }
   }
@@ -318,7 +342,10 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
       float a = 0.f, b = 0.f;
 #pragma unroll
       for (int w = 0; w < NSLOT; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
-      if (p.bnr_sums) {
+      if (defer) {                     // persistent callers: the tile's sums join the workgroup's running fp64 pair (stats_flush)
+        defer[0] += (double)a;
+        defer[1] += (double)b;
+      } else if (p.bnr_sums) {
         const int kc = p.ld0;          // channel count of the first output part
         if (n0 + tid < kc) {
           double* sp = p.bnr_sums + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * kc;
@@ -332,6 +359,30 @@ __device__ __forceinline__ void halo_epilogue(char* smem, f32x4_t (&acc)[TC][TP]
       }
     }
   }
+}
+
+// the deferred form of the epilogue's statistics atomics: thread tid < BN adds the running sums of channel n0 + tid (all tiles a
+// persistent workgroup has finished on this channel tile) to the workgroup's replica — one pair of fp64 atomics per workgroup and
+// channel instead of one per tile (layer 1: 4 tiles per workgroup, the 512 x 512 decoder layers: 16-64)
+template <int BN>
+__device__ __forceinline__ void stats_flush(const HaloParams& p, int n0, double (&d)[2]) {
+  const int tid = threadIdx.x;
+  if (tid < BN && n0 + tid < p.K) {
+    if (p.bnr_sums) {
+      const int kc = p.ld0;
+      if (n0 + tid < kc) {
+        double* sp = p.bnr_sums + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * kc;
+        atomicAdd(sp + n0 + tid, d[0]);
+        atomicAdd(sp + kc + n0 + tid, d[1]);
+      }
+    } else if (p.stats) {
+      double* sp = p.stats + (size_t)(blockIdx.x % VK_STATS_REPLICAS) * 2 * p.K;
+      atomicAdd(sp + n0 + tid, d[0]);
+      atomicAdd(sp + p.K + n0 + tid, d[1]);
+    }
+  }
+  d[0] = 0.0;
+  d[1] = 0.0;
 }
 
 template <typename T, int TH, int BN, int WGM, int WGN>
@@ -1696,6 +1747,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_colp_kernel(cons
   TileGeo g = decode(t);
   halo_index(g, h_full, h_half);
   load_halo(0, h_full, h_half);
+  double dsum[2] = {0.0, 0.0};                              // running BN sums of channel g.n0 + tid (threads < BN), see stats_flush
   int st = 0;                                               // running stage counter: weight buffer = st & 1, across tiles
   for (;;) {
     // ---- entry: the tile's first halo chunk is in areg (requested during the previous tile's last stage), no LDS-DMA is pending
@@ -1744,7 +1796,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv3x3_colp_kernel(cons
     stage(p.nchunks - 1, I1{}, std::true_type{});
     stage(p.nchunks - 1, I2{}, std::true_type{});
     // aff / relu / sc / sh now describe the prefetched chunk (chunk 0 of the next tile): exactly what its store_halo needs
-    halo_epilogue<T, TH, BN, TP, TC, NT, (BN <= 64 && TH == 16)>(smem, acc, p, g.n, g.y0, g.x0, g.n0, wrow0, wch0);
+    constexpr bool DEFER = VK_COLP_DEFER_STATS && (sizeof(T) == 2 || BN < 64);       // (the fp32 64-channel tile has no two registers left)
+    halo_epilogue<T, TH, BN, TP, TC, NT, (BN <= 64 && TH == 16)>(smem, acc, p, g.n, g.y0, g.x0, g.n0, wrow0, wch0, 0, 0, DEFER ? dsum : nullptr);
+    if (DEFER && (!more_tiles || gn.n0 != g.n0)) stats_flush<BN>(p, g.n0, dsum);
     if (!more_tiles) break;
     __syncthreads();                                        // epilogue reads of the LDS tile are over: the halo image may be rewritten
     t = tn;
