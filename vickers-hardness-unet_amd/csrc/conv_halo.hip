@@ -44,6 +44,12 @@ struct HaloSrc {
 #ifndef VK_COLP_DEFER_STATS
 #define VK_COLP_DEFER_STATS 1   // persistent K < 128 kernel: BN sums accumulate across a workgroup's tiles, one atomic pair at the end (0: per tile, r03)
 #endif
+#ifndef VK_COLQ_ILV
+#define VK_COLQ_ILV 1           // weight DMAs of a stage issued between the MFMAs of filter row 2 (0: in front of them, r03)
+#endif
+#ifndef VK_COLQ_DIAG
+#define VK_COLQ_DIAG 0          // knock-out timing builds of the pipelined K >= 128 loop (WRONG results): 1 one weight DMA per wave and stage, 2 no halo store, 4 no halo loads
+#endif
 #ifndef VK_COLQ_PRE
 #define VK_COLQ_PRE 1
 #endif
@@ -1189,16 +1195,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_colq_kernel(const H
   // weights of stage (chunk cc, filter column s) -> weight buffer s
   const uint32_t slab_bytes = (uint32_t)p.K * 64u;
   const uint32_t lane16 = (uint32_t)lane * 16u;
-  auto dma_b = [&](int cc, int s) {
+  auto dma_b = [&](int cc, int s, uint32_t oob = 0u) {       // oob = kOOB: issued, but out of the descriptor's range (fetches nothing; keeps the vmcnt pattern uniform)
 #pragma unroll
-    for (int i = 0; i < Cfg::DMAW; ++i) {
+    for (int i = 0; i < ((VK_COLQ_DIAG & 1) ? 1 : Cfg::DMAW); ++i) {      // diagnostic bit 1: one piece per wave and stage (timing only)
       const int pc = wave + i * NW;
       const int r = pc / (BN / 16), sub = pc - r * (BN / 16);
       const int tap = p.flip ? 8 - (3 * r + s) : 3 * r + s;
       const uint32_t goff = (uint32_t)(cc * 9 + tap) * slab_bytes + (uint32_t)(n0 + sub * 16) * 64u;
       char* dst = Bbuf + s * Cfg::B_BYTES + (r * BN + sub * 16) * 64;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, lane16, goff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, lane16 | oob, goff, 0, 0);     // (the VECTOR offset is the range-checked one)
     }
+  };
+
+
+  auto dma_one = [&](int cc, int s, int i, uint32_t oob) {
+    const int pc = wave + i * NW;
+    const int r = pc / (BN / 16), sub = pc - r * (BN / 16);
+    const int tap = p.flip ? 8 - (3 * r + s) : 3 * r + s;
+    const uint32_t goff = (uint32_t)(cc * 9 + tap) * slab_bytes + (uint32_t)(n0 + sub * 16) * 64u;
+    char* dst = Bbuf + s * Cfg::B_BYTES + (r * BN + sub * 16) * 64;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, lane16 | oob, goff, 0, 0);
   };
 
   const int wrow0 = (wave / WGN) * TP;
@@ -1275,16 +1291,39 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_colq_kernel(const H
       __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1 + TC + TP / 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-      if (s == 1 && next_chunk) store_halo(Anext);
+      if (s == 1 && next_chunk && !(VK_COLQ_DIAG & 2)) store_halo(Anext);          // diagnostic bit 2: no operand transform / halo store in the loop
       // every wave: its reads of this stage's weights / halo rows have returned, its halo stores are in LDS, and of its vector
       // memory operations only the DMAW youngest (the weights of stage st + 2) may still be in flight
       asm volatile("" ::: "memory");
-      if (next_chunk) __builtin_amdgcn_s_waitcnt(kWaitPart);
+      if (VK_COLQ_ILV) __builtin_amdgcn_s_waitcnt(kWaitPart);     // the last chunk issues its (out-of-range) DMAs too
+      else if (next_chunk) __builtin_amdgcn_s_waitcnt((VK_COLQ_DIAG & 1) ? ((1 & 0xF) | 0x70) : kWaitPart);
       else __builtin_amdgcn_s_waitcnt(kWaitAll);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if (VK_COLQ_ILV) {
+        // r04: the weight DMAs of the stage are issued BETWEEN the MFMAs of filter row 2, not in front of them: all eight
+        // waves leave the barrier together and queue 24 vector-memory instructions at the CU's address unit while no MFMA is in
+        // flight (knock-out builds: 16 of them cost 12-15 % of the kernel).  Needs one basic block: the DMAs are issued in the last
+        // chunk as well, out of the descriptor's range
+        if (s == 0 && next_chunk && !(VK_COLQ_DIAG & 4)) load_halo(cc + 1);
+#pragma unroll
+        for (int a = 0; a < TC; ++a) W0n[a] = rd(Bn + (a * 16) * 64);
+        const uint32_t oob = next_chunk ? 0u : kOOB;
+        constexpr int NT2 = TC * TP, GRP = NT2 / (Cfg::DMAW + 1);
+#pragma unroll
+        for (int i = 0; i <= Cfg::DMAW; ++i) {
+          const int lo = i * GRP, hi = i == Cfg::DMAW ? NT2 : (i + 1) * GRP;
+#pragma unroll
+          for (int q = lo; q < hi; ++q) acc[q / TP][q % TP] = Mma<T>::run(W2[q / TP], X[q % TP + 2], acc[q / TP][q % TP]);
+          if (i < Cfg::DMAW) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma_one(cc + 1, s, i, oob);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
       if (next_chunk) {
-        if (s == 0) load_halo(cc + 1);                      // in front of the DMAs: those stay the youngest operations
+        if (s == 0 && !(VK_COLQ_DIAG & 4)) load_halo(cc + 1);   // in front of the DMAs: those stay the youngest operations (diagnostic bit 4: no halo loads)
         dma_b(cc + 1, s);                                   // stage st + 3 -> the buffer every wave has just finished reading
       }
       // -- filter row 2; under it: the next stage's filter row 0 (its weights became visible with the barrier)
@@ -1293,6 +1332,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_colq_kernel(const H
         for (int a = 0; a < TC; ++a) W0n[a] = rd(Bn + (a * 16) * 64);
       }
       mfma_row(W2, 2);
+      }
       if (more) {
 #pragma unroll
         for (int h = 0; h < TP; ++h) X[h] = Xn[h];
@@ -1301,6 +1341,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 1) void conv3x3_colq_kernel(const H
       }
     }
   }
+  if (VK_COLQ_ILV) __builtin_amdgcn_s_waitcnt(kWaitAll);    // the last chunk's out-of-range DMAs have retired
   __syncthreads();                                          // every wave is done with the operand buffers: the epilogue reuses them
 
   if (p.ksplit > 1) {
@@ -2861,6 +2902,9 @@ static int col_select(const HaloParams& p, hipStream_t st) {
     if (alt == 7 || (alt != 2 && tiles16 * kt < 256))
       return pipe == 2 ? launch_col<T, 8, 128, 2, 4, true, 1, 2>(p, st)
              : pipe    ? launch_col<T, 8, 128, 2, 4, true, 1, 1>(p, st) : launch_col<T, 8, 128, 2, 4, true, 2>(p, st);
+    // experiment (VK_COL_ALT=9): 8 rows x 32 channels per wave — 16 instead of 18 fragment reads per stage and wave (the K >= 128 loop asks
+    // 75 % of the LDS read bandwidth at the full MFMA rate: DESIGN.md section 6)
+    if (alt == 9) return launch_col<T, 16, 128, 2, 4, true, 1, 1>(p, st);
     return pipe == 2 ? launch_col<T, 16, 128, 4, 2, true, 1, 2>(p, st)       // 8 waves, 4 rows x 64 channels per wave
            : pipe    ? launch_col<T, 16, 128, 4, 2, true, 1, 1>(p, st) : launch_col<T, 16, 128, 4, 2, true, 2>(p, st);
   }
