@@ -28,6 +28,9 @@
 #define VK_WH_PIPE 0
 #endif
 // -DVK_WH_ZDMA=0: dz of the 64 x 64 tap-split configuration staged through registers + ds_write_b128 as in r03 (A/B builds through VK_LIB)
+#ifndef VK_WH_XCD
+#define VK_WH_XCD 1
+#endif
 #ifndef VK_WH_ZDMA
 #define VK_WH_ZDMA 1
 #endif
@@ -539,7 +542,12 @@ template <typename T>
 __global__ __launch_bounds__(512) void wgrad_halo_batch_kernel(const WhParams* __restrict__ layers, const WhSeg* __restrict__ segs,
                                                                const int* __restrict__ wg_first, float* slab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int s0 = wg_first[blockIdx.x], s1 = wg_first[blockIdx.x + 1];
+  // workgroups go round-robin over the 8 XCDs (each with its own L2): XCD x takes the x-th eighth of the unit list, so that the
+  // workgroups walking neighbouring output tiles of a layer — which read the same dz tiles (same K tile) or the same operand tiles
+  // (same C tile) at about the same time — share one L2 (VK_WH_XCD=0: workgroup b takes range b, r03)
+  int b = (int)blockIdx.x;
+  if (VK_WH_XCD && (gridDim.x & 7) == 0) b = (b & 7) * (int)(gridDim.x >> 3) + (b >> 3);
+  const int s0 = wg_first[b], s1 = wg_first[b + 1];
   for (int s_ = s0; s_ < s1; ++s_) {
     const WhSeg sg = segs[s_];
     const WhParams p = layers[sg.layer];
