@@ -195,6 +195,13 @@ int vk_conv_wgrad_batch(const vk_conv_desc* descs, const void* const* dz, float*
                         size_t tables_bytes, void* workspace, size_t workspace_bytes, void* stream);
 int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const void* dz, float* dw_krsc3, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* The same with the stem BatchNorm's backward apply folded in (16-bit types; VK_ERR_UNSUPPORTED otherwise: run vk_bn_bwd_apply +
+ * vk_stem_wgrad): g = the masked upstream gradient (what vk_maxpool_bwd_bn_reduce stored), z = the stem convolution's output,
+ * coef_abc = [3][64] from vk_bn_bwd_coeffs; the kernel forms dz = a*g + b*z + c while it stages its operand — the stem has no data
+ * gradient, so dz has no other reader and the 3-tensor apply pass (reference: autograd's batch_norm backward node behind
+ * train.py:448 -> encoder.bn1) disappears. */
+int vk_stem_wgrad_bn(vk_dtype dtype, int N, int H, int W, const void* x4, const void* g, const void* z, const float* coef_abc,
+                     float* dw_krsc3, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The steps either side of model(x) in the inference wrappers, one fused pass each.

@@ -727,6 +727,41 @@ def test_stem_wgrad(dtn, S):
     assert torch.equal(outs[1], outs[2])     # fixed summation order
 
 
+@pytest.mark.parametrize("dtn", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("S", [64, 96, 160])
+def test_stem_wgrad_with_folded_bn_apply(dtn, S):
+    """vk_stem_wgrad_bn forms dz = a*g + b*z + c while it stages its operand (r04: the stem's BatchNorm-backward apply pass has no other
+    reader; reference: autograd's batch_norm backward + convolution-backward-weight nodes of encoder.bn1 / encoder.conv1 behind
+    train.py:448).  Against the two-launch form (vk_bn_bwd_apply, then vk_stem_wgrad) on the same slab workspace: the same fp32
+    expression, the same rounding of dz, the same summation order — bit-identical; sizes whose last tiles are partial (the constant c
+    must not leak into the padding).  fp32 reports VK_ERR_UNSUPPORTED (the engine then runs the two launches)."""
+    dt = DT[dtn]
+    N = 2
+    x = gen(N, 3, S, S, seed=63)
+    x4 = torch.zeros((N, S, S, 4), dtype=dt, device=dev())
+    x4[..., :3] = D(x.permute(0, 2, 3, 1).to(dt))
+    g = to_nhwc(gen(N, 64, S // 2, S // 2, seed=64), dt)
+    z = to_nhwc(gen(N, 64, S // 2, S // 2, seed=65), dt)
+    gg = torch.Generator().manual_seed(66)
+    coef = D(torch.cat([0.5 + torch.rand(64, generator=gg), 0.1 * torch.randn(64, generator=gg), 0.05 * torch.randn(64, generator=gg)]).float())
+    ws = torch.empty(16 << 20, dtype=torch.uint8, device=dev())
+    dw_f = torch.zeros(64, 7, 7, 3, dtype=torch.float32, device=dev())
+    rc = vk.lib().vk_stem_wgrad_bn(L_.dtype_code(dt), N, S, S, x4.data_ptr(), g.data_ptr(), z.data_ptr(), coef.data_ptr(), dw_f.data_ptr(),
+                                  ws.data_ptr(), ws.numel(), st())
+    if dt == torch.float32:
+        assert rc == -3          # VK_ERR_UNSUPPORTED (include/vk_unet.h)
+        return
+    vk._lib.check(rc)
+    dz = torch.empty_like(g)
+    vk._lib.check(vk.lib().vk_bn_bwd_apply(L_.dtype_code(dt), N * (S // 2) * (S // 2), 64, g.data_ptr(), z.data_ptr(), 0, None, None, None,
+                                           coef.data_ptr(), dz.data_ptr(), None, 0, st()))
+    dw_2 = torch.zeros(64, 7, 7, 3, dtype=torch.float32, device=dev())
+    vk._lib.check(vk.lib().vk_stem_wgrad(L_.dtype_code(dt), N, S, S, x4.data_ptr(), dz.data_ptr(), dw_2.data_ptr(), ws.data_ptr(), ws.numel(), st()))
+    torch.cuda.synchronize()
+    assert dw_2.abs().max().item() > 0
+    assert torch.equal(dw_f, dw_2), (dw_f - dw_2).abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------------ BN / pool / tails
 def test_bn_finalize_train_and_eval():
     Cc, cnt = 64, 1000.0

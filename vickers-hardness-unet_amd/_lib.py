@@ -100,6 +100,7 @@ SIGNATURES = {
     "vk_conv_wgrad_batch_supports": (ci, [P(vk_conv_desc)]),
     "vk_conv_wgrad_batch": (ci, [P(vk_conv_desc), P(vp), P(vp), ci, ci, vp, sz, vp, sz, vp]),
     "vk_stem_wgrad": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]),
+    "vk_stem_wgrad_bn": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, sz, vp]),
     "vk_letterbox_preprocess": (ci, [P(vk_letterbox_desc), vp, vp, vp]),
     "vk_letterbox_postprocess_mask": (ci, [P(vk_letterbox_desc), vp, cf, vp, vp]),
     "vk_letterbox_postprocess_prob": (ci, [P(vk_letterbox_desc), vp, vp, vp]),

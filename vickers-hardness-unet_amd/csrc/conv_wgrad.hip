@@ -440,13 +440,18 @@ int conv_wgrad_impl(const vk_conv_desc* d, const void* dz, float* dw, void* work
 struct StemWgParams {
   const void* x4;
   const void* dz;
+  const void* z;          // BNA form: dz is the masked upstream gradient g, the operand is a*g + b*z + c (BatchNorm backward apply, folded in)
+  const float* coef;      // [3][64]: a, b, c
   float* dw;
   float* slab;            // [gridDim.x][64 * 147] per-workgroup partial results (nullptr: fp32 atomics into dw)
   uint32_t x_bytes, dz_bytes;
   int N, H, W, Ho, Wo, tiles_x, tiles_y, ntiles;
 };
 
-template <typename T>
+// BNA (r04): the stem's BatchNorm-backward apply pass exists only to feed this kernel (the stem has no data gradient): instead of
+// reading g and z (2 x 268 MB at bs 32), writing dz and reading it again here, the kernel reads g and z itself and forms
+// dz = a*g + b*z + c (same fp32 expression and rounding as k_bn_bwd_apply) while staging — the 805 MB pass and its launch go
+template <typename T, bool BNA>
 __global__ __launch_bounds__(256) void k_stem_wgrad(const StemWgParams p) {
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int ZSB = 160;                   // dz pixel row: 64 k x 2 B + 32 pad (conflict-free transposed reads)
@@ -460,8 +465,20 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemWgParams p) {
   const __amdgpu_buffer_rsrc_t rsz = make_rsrc(p.dz, p.dz_bytes);
 
   u32x4_t zr[4], zr_n[4];
+  u32x4_t qr[BNA ? 4 : 1], qr_n[BNA ? 4 : 1];       // BNA: the z vectors beside the g vectors
+  uint32_t okm = 0, okm_n = 0;                       // BNA: which of the four vectors lie inside the image (c must not leak into the padding)
   u32x2_t xr[4], xr_n[4];
-  auto fetch = [&](int t, u32x4_t (&zv)[4], u32x2_t (&xv)[4]) {
+  const __amdgpu_buffer_rsrc_t rsq = make_rsrc(BNA ? p.z : p.dz, p.dz_bytes);
+  float ca[8], cb[8], cc[8];                         // this thread's 8 channels: vec = tid & 7 in every vector it stages
+  if (BNA) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ca[j] = p.coef[(tid & 7) * 8 + j];
+      cb[j] = p.coef[64 + (tid & 7) * 8 + j];
+      cc[j] = p.coef[128 + (tid & 7) * 8 + j];
+    }
+  }
+  auto fetch = [&](int t, u32x4_t (&zv)[4], u32x4_t (&qv)[BNA ? 4 : 1], uint32_t& okv, u32x2_t (&xv)[4]) {
     int bt = t;
     const int tx = bt % p.tiles_x;
     bt /= p.tiles_x;
@@ -474,7 +491,13 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemWgParams p) {
       const int px = idx >> 3, vec = idx & 7;
       const int y = y0 + (px >> 5), x = x0 + (px & 31);
       const bool ok = y < p.Ho && x < p.Wo;
-      zv[i] = buf_load16(rsz, ok ? (uint32_t)(((n * p.Ho + y) * p.Wo + x) * 64 + vec * 8) * 2u : kOOB);
+      const uint32_t off = ok ? (uint32_t)(((n * p.Ho + y) * p.Wo + x) * 64 + vec * 8) * 2u : kOOB;
+      zv[i] = buf_load16(rsz, off);
+      if (BNA) {
+        qv[i] = buf_load16(rsq, off);
+        if (i == 0) okv = 0;
+        okv |= (ok ? 1u : 0u) << i;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -485,13 +508,23 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemWgParams p) {
       xv[i] = __builtin_amdgcn_raw_buffer_load_b64(rsx, ok ? (uint32_t)(((n * p.H + iy) * p.W + ix) * 4) * 2u : kOOB, 0, 0);
     }
   };
-  auto stage = [&](int st, const u32x4_t (&zv)[4], const u32x2_t (&xv)[4]) {
+  auto stage = [&](int st, const u32x4_t (&zv)[4], const u32x4_t (&qv)[BNA ? 4 : 1], uint32_t okv, const u32x2_t (&xv)[4]) {
     char* Zs = smem + st * STAGE;
     char* Xs = Zs + Z_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 256;
-      *reinterpret_cast<u32x4_t*>(Zs + (idx >> 3) * ZSB + (idx & 7) * 16) = zv[i];
+      u32x4_t v = zv[i];
+      if (BNA) {
+        float g[8], zf[8], o[8];
+        Vec16<T>::unpack(zv[i], g);
+        Vec16<T>::unpack(qv[i], zf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(ca[j], g[j], fmaf(cb[j], zf[j], cc[j]));
+        v = Vec16<T>::pack(o);
+        if (!((okv >> i) & 1u)) v = u32x4_t{0, 0, 0, 0};
+      }
+      *reinterpret_cast<u32x4_t*>(Zs + (idx >> 3) * ZSB + (idx & 7) * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -512,13 +545,13 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemWgParams p) {
 
   int t = blockIdx.x;
   if (t < p.ntiles) {
-    fetch(t, zr, xr);
-    stage(0, zr, xr);
+    fetch(t, zr, qr, okm, xr);
+    stage(0, zr, qr, okm, xr);
   }
   __syncthreads();
   for (int it = 0; t < p.ntiles; t += gridDim.x, ++it) {
     const bool has_next = t + (int)gridDim.x < p.ntiles;
-    if (has_next) fetch(t + gridDim.x, zr_n, xr_n);
+    if (has_next) fetch(t + gridDim.x, zr_n, qr_n, okm_n, xr_n);
     const char* Zs = smem + (it & 1) * STAGE;
     const char* Xs = Zs + Z_BYTES;
 #pragma unroll
@@ -538,7 +571,7 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemWgParams p) {
         }
     }
     if (has_next) {
-      stage((it + 1) & 1, zr_n, xr_n);                     // that buffer was last read one iteration ago, before the barrier below
+      stage((it + 1) & 1, zr_n, qr_n, okm_n, xr_n);        // that buffer was last read one iteration ago, before the barrier below
 #pragma unroll
       for (int i = 0; i < 4; ++i) { zr[i] = zr_n[i]; xr[i] = xr_n[i]; }
     }
@@ -563,12 +596,14 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemWgParams p) {
 }
 
 int stem_wgrad_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
-                    hipStream_t st) {
+                    hipStream_t st, const void* bn_z = nullptr, const float* bn_coef = nullptr) {
   VK_CHECK_ARG(x4 && dz && dw, "vk_stem_wgrad: null argument");
   const int eb = dt == VK_F32 ? 4 : 2;
-  if (dt != VK_F32 && !getenv("VK_STEM_WGRAD_TAPS") && (size_t)N * (H / 2) * (W / 2) * 64 * 2 < (1ull << 31)) {
+  const bool tile = dt != VK_F32 && !getenv("VK_STEM_WGRAD_TAPS") && (size_t)N * (H / 2) * (W / 2) * 64 * 2 < (1ull << 31);
+  if (bn_z && !tile) return VK_ERR_UNSUPPORTED;        // the folded BatchNorm apply lives in the 16-bit tile kernel only
+  if (tile) {
     StemWgParams q;
-    q.x4 = x4; q.dz = dz; q.dw = dw;
+    q.x4 = x4; q.dz = dz; q.dw = dw; q.z = bn_z; q.coef = bn_coef;
     q.N = N; q.H = H; q.W = W; q.Ho = H / 2; q.Wo = W / 2;
     q.x_bytes = (uint32_t)((size_t)N * H * W * 4 * 2);
     q.dz_bytes = (uint32_t)((size_t)N * q.Ho * q.Wo * 64 * 2);
@@ -583,10 +618,16 @@ int stem_wgrad_impl(vk_dtype dt, int N, int H, int W, const void* x4, const void
       if ((size_t)nb > cap) nb = (int)cap;
       q.slab = (float*)workspace;
     }
-    static const std::string tag = "wgrad_stem_16b";
-    vkh::ProfScope ps(tag.c_str(), st, 2.0 * (double)N * q.Ho * q.Wo * 64.0 * 147.0, ((double)N * H * W * 4 + (double)N * q.Ho * q.Wo * 64) * 2.0 + 64.0 * 147 * 4);
-    if (dt == VK_BF16) hipLaunchKernelGGL(k_stem_wgrad<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, q);
-    else hipLaunchKernelGGL(k_stem_wgrad<f16_t>, dim3((unsigned)nb), dim3(256), 0, st, q);
+    static const std::string tag = "wgrad_stem_16b", tag_bn = "wgrad_stem_16b_bn";
+    vkh::ProfScope ps(bn_z ? tag_bn.c_str() : tag.c_str(), st, 2.0 * (double)N * q.Ho * q.Wo * 64.0 * 147.0,
+                      ((double)N * H * W * 4 + (double)N * q.Ho * q.Wo * 64 * (bn_z ? 2 : 1)) * 2.0 + 64.0 * 147 * 4);
+    if (bn_z) {
+      if (dt == VK_BF16) hipLaunchKernelGGL((k_stem_wgrad<bf16_t, true>), dim3((unsigned)nb), dim3(256), 0, st, q);
+      else hipLaunchKernelGGL((k_stem_wgrad<f16_t, true>), dim3((unsigned)nb), dim3(256), 0, st, q);
+    } else {
+      if (dt == VK_BF16) hipLaunchKernelGGL((k_stem_wgrad<bf16_t, false>), dim3((unsigned)nb), dim3(256), 0, st, q);
+      else hipLaunchKernelGGL((k_stem_wgrad<f16_t, false>), dim3((unsigned)nb), dim3(256), 0, st, q);
+    }
     if (q.slab) launch_slab_reduce(out_elems / 4, nb, q.slab, dw, st);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
@@ -623,4 +664,9 @@ extern "C" int vk_conv_wgrad(const vk_conv_desc* d, const void* dz, float* dw, v
 extern "C" int vk_stem_wgrad(vk_dtype dtype, int N, int H, int W, const void* x4, const void* dz, float* dw_krsc3, void* workspace,
                              size_t workspace_bytes, void* stream) {
   return vk::stem_wgrad_impl(dtype, N, H, W, x4, dz, dw_krsc3, workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int vk_stem_wgrad_bn(vk_dtype dtype, int N, int H, int W, const void* x4, const void* g, const void* z, const float* coef_abc,
+                                float* dw_krsc3, void* workspace, size_t workspace_bytes, void* stream) {
+  VK_CHECK_ARG(z && coef_abc, "vk_stem_wgrad_bn: null argument");
+  return vk::stem_wgrad_impl(dtype, N, H, W, x4, g, dw_krsc3, workspace, workspace_bytes, (hipStream_t)stream, z, coef_abc);
 }

@@ -1303,7 +1303,20 @@ int backward_stem(vk_unet* h, hipStream_t st) {
     BnL& b = h->bns[stem.bn];
     RET_IF(vk_maxpool_bwd_bn_reduce(h->cfg.dtype, N, S / 2, SW / 2, 64, h->ws + h->off_gpool, (const uint8_t*)(h->ws + h->off_argmax), stem.z,
                                     b.scale, b.shift, stem.g, b.bsums, st));
-    RET_IF(bn_relu_bwd_inplace(h, stem, true, st));
+    // r04: the stem's dz has ONE reader, the weight gradient below (no data gradient: the input needs none) — the 16-bit kernel forms
+    // dz = a*g + b*z + c itself while staging, so the apply pass (g, z -> dz: 805 MB at bs 32) is not run.  VK_NO_STEM_BNA=1: the pass
+    if (h->cfg.dtype != VK_F32 && !getenv("VK_NO_STEM_BNA")) {
+      RET_IF(vk_bn_bwd_coeffs(64, b.bsums, b.count, h->params + b.g_off, b.mean, b.invstd, h->grads + b.g_off, h->grads + b.b_off, b.coef, st));
+      hipStream_t ws;
+      RET_IF(wgrad_stream(h, st, &ws));
+      const int rc = vk_stem_wgrad_bn(h->cfg.dtype, N, S, SW, h->ws + h->off_x4, stem.g, stem.z, b.coef, h->grads + stem.w_off,
+                                      h->ws + h->off_wslab, VK_WGRAD_WORKSPACE_BYTES, ws);
+      if (rc != VK_ERR_UNSUPPORTED) return rc;
+      // (shape outside the tile kernel: coefficients are in place, finish with the separate apply pass)
+      RET_IF(vk_bn_bwd_apply(h->cfg.dtype, (size_t)N * (S / 2) * (SW / 2), 64, stem.g, stem.z, 0, b.scale, b.shift, nullptr, b.coef, stem.g, nullptr, 0, st));
+    } else {
+      RET_IF(bn_relu_bwd_inplace(h, stem, true, st));
+    }
   }
   hipStream_t ws;
   RET_IF(wgrad_stream(h, st, &ws));
