@@ -833,3 +833,38 @@ def test_training_steps_are_bit_reproducible(dtype):
     assert torch.equal(la, lb)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("n,h,w", [(4, 128, 128), (2, 96, 160)])
+def test_stem_bn_apply_folded_into_weight_gradient_matches_two_launches(monkeypatch, dtype, n, h, w):
+    """r04: the stem's BatchNorm-backward apply pass is folded into the stem weight gradient (vk_stem_wgrad_bn: dz = a*g + b*z + c formed
+    while the kernel stages its operand; reference: autograd's batch_norm backward + convolution-backward-weight nodes of encoder.bn1 /
+    encoder.conv1 behind train.py:448).  VK_NO_STEM_BNA=1 runs the apply pass and the plain weight gradient instead.  Same seed and
+    batches, two steps each way: the same fp32 expression, rounding and summation order — every parameter, buffer and loss must agree
+    bit for bit (square and non-square inputs: the last tiles are partial, the constant c must not leak into the padding)."""
+    from oracle import unet_oracle as O
+    finals = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("VK_NO_STEM_BNA", "1")
+        else:
+            monkeypatch.delenv("VK_NO_STEM_BNA", raising=False)
+        O.set_seed(35)
+        m = vk.Unet(encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=1, activation=None).to(dev()).train()
+        opt = vk.adamw_for(m, lr=1e-3, weight_decay=1e-4)
+        losses = []
+        for step in range(2):
+            g = torch.Generator().manual_seed(700 + step)
+            x = torch.randn(n, 3, h, w, generator=g)
+            y = (torch.rand(n, 1, h, w, generator=g) > 0.7).float()
+            opt.zero_grad(set_to_none=True)
+            losses.append(m.loss_and_backward(x.to(dev()), y.to(dev()), grad_scale=1024.0 if dtype == torch.float16 else 1.0, dtype=dtype).clone())
+            opt.step(grad_scale=torch.full((1,), 1024.0, device=dev()) if dtype == torch.float16 else None)
+        torch.cuda.synchronize()
+        finals.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, losses))
+    (a, la), (b, lb) = finals
+    for u, v in zip(la, lb):
+        assert torch.equal(u, v), (u, v)
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, (a[k].float() - b[k].float()).abs().max().item())
